@@ -1,0 +1,156 @@
+/* libkdip_hip -- C ABI of the MI355X-native guided-diffusion inverse-problem hot path.
+ *
+ * The reference (xypeng9903/k-diffusion-inverse-problems) is pure Python: its plug-in
+ * surface is duck typing + two decorator registries and it has no FFI.  This header is the
+ * boundary a maintainer would bind (ctypes stub in INTEGRATION.md); every entry point
+ * names the reference interface it replaces (file:line under the reference root).
+ *
+ * Conventions
+ *   - every function returns an int status: 0 = OK, < 0 = error (enum below); the message of
+ *     the last error on the calling thread is returned by kdip_last_error().  No exceptions,
+ *     no aborts across the ABI.
+ *   - pointers named *_dev are device pointers the CALLER owns (e.g. torch tensors'
+ *     data_ptr()); the library never frees or retains them beyond the call.  Work is
+ *     enqueued on `stream` (a hipStream_t passed as void*); the caller keeps buffers alive
+ *     until the stream is synchronised.  Pointers named *_host are host memory and are
+ *     consumed before the call returns.
+ *   - image tensors are fp32, NCHW, contiguous: [B,3,H,W] (measurement of the SR operator
+ *     [B,3,H/sf,W/sf]); B independent problems that share one sigma per call.
+ *   - handles are not thread-safe; one per (process, device).
+ */
+#ifndef KDIP_H
+#define KDIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { KDIP_OK = 0, KDIP_ERR_ARG = -1, KDIP_ERR_HIP = -2, KDIP_ERR_STATE = -3, KDIP_ERR_NOMEM = -4,
+       KDIP_ERR_UNSUPPORTED = -5 };
+enum { KDIP_F32 = 0, KDIP_BF16 = 1 };                 /* storage / MFMA input type of the UNet */
+enum { KDIP_OP_INPAINT = 0, KDIP_OP_BLUR = 1, KDIP_OP_SR = 2 };
+enum { KDIP_OT_NONE = 0, KDIP_OT_DWT = 1, KDIP_OT_DCT = 2 };
+
+const char* kdip_last_error(void);
+int kdip_version(void);
+
+/* ------------------------------------------------------------------ UNet (rows A4-A6, A14)
+ * Replaces guided_diffusion.unet.UNetModel (guided_diffusion/unet.py:396-668) as built by
+ * script_util.create_model (guided_diffusion/script_util.py:130-184) with the defaults of
+ * condition/diffpir_utils/utils_model.py:353-387, and -- for kdip_unet_vjp -- the
+ * torch.autograd.grad(..., x) calls of condition/condition.py:136,146,155,172. */
+typedef struct kdip_unet kdip_unet;
+
+/* attention_ds: downsample rates with attention (image_size // attention_resolution). */
+int kdip_unet_create(int device, int dtype, int image_size, int in_channels, int model_channels, int out_channels,
+                     int num_res_blocks, const int* attention_ds, int n_attention_ds, const int* channel_mult,
+                     int n_channel_mult, int num_head_channels, kdip_unet** out);
+void kdip_unet_destroy(kdip_unet* u);
+/* One parameter of the reference state_dict, by its key (e.g. "input_blocks.3.0.in_layers.2.weight",
+ * plus optional "out_cov.weight"/"out_cov.bias" of OpenAIDenoiserV2, k_diffusion/external.py:141);
+ * fp32 host data in PyTorch layout.  Replaces nn.Module.load_state_dict
+ * (sample_condition_openai.py:130-132). */
+int kdip_unet_load(kdip_unet* u, const char* name, const float* data_host, const long* shape, int ndim);
+/* Repack all weights into MFMA fragment order (forward + dgrad copies) and upload. */
+int kdip_unet_finalize(kdip_unet* u);
+/* out = UNet(x * in_scale, t).  x_dev [B,in_ch,S,S], t_dev [B] (fractional allowed),
+ * out_dev [B,out_ch,S,S]; optional cov_out_dev [B,6,S,S] = out_cov(h) and feature_dev
+ * [B,model_ch,S,S] = h (UNetModel.forward(..., return_feature=True), unet.py:665-666).
+ * Activations needed by kdip_unet_vjp are stashed inside the handle. */
+int kdip_unet_forward(kdip_unet* u, void* stream, const float* x_dev, const float* t_dev, int B, float in_scale,
+                      float* out_dev, float* cov_out_dev, float* feature_dev);
+/* gx = (d out / d (x*in_scale))^T cot for the last kdip_unet_forward.  cot_dev [B,out_ch,S,S],
+ * gx_dev [B,in_ch,S,S].  May be called repeatedly. */
+int kdip_unet_vjp(kdip_unet* u, void* stream, const float* cot_dev, float* gx_dev);
+/* bytes of device workspace currently held for batch B (allocated lazily, grows monotonically). */
+long kdip_unet_workspace_bytes(kdip_unet* u, int B);
+
+/* ------------------------------------------------- operators / solvers (rows A9-A13)
+ * One context per measurement operator instance (condition/measurements.py:86-244). */
+typedef struct kdip_op kdip_op;
+int kdip_op_create(int device, int kind, int image_size, int scale_factor, float sigma_s, kdip_op** out);
+void kdip_op_destroy(kdip_op* op);
+/* PSF -> OTF on device: p2o + fft2 (condition/diffpir_utils/utils_sisr.py:22-41,79-96). */
+int kdip_op_set_psf(kdip_op* op, const float* psf_host, int kh, int kw);
+/* Optional rank-1 factors of the PSF (psf = krow (x) kcol): enables the LDS-staged separable
+ * stencil for A / A^T instead of the FFT (same circular convolution, measurements.py:139-148). */
+int kdip_op_set_separable(kdip_op* op, const float* krow_host, const float* kcol_host, int taps);
+/* mask [3,S,S] in {0,1} (InpaintingOperator.mask, measurements.py:209). */
+int kdip_op_set_mask(kdip_op* op, const float* mask_host);
+/* OrthoTransform type for the posterior covariance basis (condition/utils.py:50-67). */
+int kdip_op_set_ortho(kdip_op* op, int ortho_type);
+/* copies the complex OTF [S,S] (float2) to otf_dev: operator.pre_calculated[0]. */
+int kdip_op_get_otf(kdip_op* op, void* stream, float* otf_dev);
+/* A x / A^T y of the solver model: circular blur (BLUR), blur then ::sf decimation (SR),
+ * mask multiply (INPAINT).  SR adjoint = operator.transpose (measurements.py:114-120). */
+int kdip_op_apply(kdip_op* op, void* stream, const float* x_dev, int B, int adjoint, float* out_dev);
+/* mat = A^T (sigma_s^2 I + A C A^T)^-1 (y - A x0)   (condition/condition.py:317-439).
+ * var_tensor_dev == NULL: C = var_scalar * I, closed form.  Otherwise C = W^-1 diag(var) W,
+ * batched per-sample CG (scipy cg tol=1e-4, maxiter=1000 semantics); cg_iters_host/cg_info_host
+ * (may be NULL) receive per-sample iteration counts and scipy-style info (0 = converged). */
+int kdip_op_solve(kdip_op* op, void* stream, const float* y_dev, const float* x0_dev, float var_scalar,
+                  const float* var_tensor_dev, int B, float* mat_dev, int* cg_iters_host, int* cg_info_host);
+/* OrthoTransform.__call__ / .inv on [B,3,S,S] (condition/utils.py:59-67,88-139). */
+int kdip_op_ortho(kdip_op* op, void* stream, const float* x_dev, int B, int inverse, float* out_dev);
+
+/* ---- stand-alone operator kernels ---- */
+/* out[b, j] = x[b].flat[idx[j]] and its adjoint (InpaintingOperator flatten paths, measurements.py:217-236). */
+int kdip_gather(void* stream, const float* x_dev, const long* idx_dev, long nidx, long per_sample, int B, float* out_dev);
+int kdip_scatter(void* stream, const float* y_dev, const long* idx_dev, long nidx, long per_sample, int B, float* out_dev);
+/* out = x * mask (mask [3,S,S] broadcast over the batch). */
+int kdip_mask_mul(void* stream, const float* x_dev, const float* mask_dev, int B, long chw, float* out_dev);
+/* One axis of Resizer.forward (condition/dps_utils/resizer.py:55-74) and its adjoint:
+ * weights/fov [n_out, taps]; axis 1 = W (x [planes, other, n_in]), axis 0 = H (x [planes, n_in, other]). */
+int kdip_resize_axis(void* stream, const float* x_dev, const float* w_dev, const int* fov_dev, int taps, int n_in,
+                     int n_out, int other, int axis, long planes, int adjoint, float* out_dev);
+/* dense circular PSF convolution / correlation in the spatial domain (LDS-staged tile + halo). */
+int kdip_blur_dense(void* stream, const float* x_dev, const float* psf_dev, int ks, int S, long planes, int adjoint,
+                    float* out_dev);
+/* raw 2-D FFT of [planes,S,S] (complex as interleaved float2): torch.fft.fft2 / ifft2. */
+int kdip_fft2(void* stream, int S, const float* in_dev, int real_in, float* out_dev, int real_out, long planes,
+              int inverse, float* tmp_dev);
+
+/* ------------------------------------------------------ guidance algebra (rows A3-A8) */
+/* p_mean_variance epilogue of ConditionOpenAIDenoiser.uncond_pred (condition/condition.py:231-248,
+ * gaussian_diffusion.py:262-276,293-333).  tables7 = {c_in, sqrt(1/ac_t), sqrt(1/ac_t - 1), log beta_t,
+ * log post_var_clipped_t, post_var_t, post_mean_coef1_t}.  var_dev may be NULL (scalar-variance branch). */
+int kdip_x0_epilogue_v1(void* stream, const float* unet_out_dev, const float* x_dev, int B, long HW,
+                        const float* tables7_host, float* x0_mean_dev, float* x0_raw_dev, float* var_dev);
+/* ConditionOpenAIDenoiserV2.uncond_pred (condition/condition.py:287-300). */
+int kdip_x0_epilogue_v2(void* stream, const float* unet_out_dev, const float* cov_out_dev, const float* x_dev, int B,
+                        long HW, float sigma, int want_var, float* x0_mean_dev, float* x0_var_dev, float* theta_var_dev);
+/* cotangent on the 6 UNet output channels for d<ghat, x0_mean>/dx. */
+int kdip_vjp_cotangent_v1(void* stream, const float* ghat_dev, const float* x0_raw_dev, int B, long HW,
+                          float sqrt_recipm1, float* cot6_dev, float* g_raw_dev);
+int kdip_vjp_cotangent_v2(void* stream, const float* ghat_dev, int B, long HW, float* cot6_dev);
+/* hat = clamp(x0 + coef * (a * g_direct + b * unet_vjp), -1, 1); either gradient may be NULL. */
+int kdip_guidance_combine(void* stream, const float* x0_mean_dev, const float* g_direct_dev, float a,
+                          const float* unet_vjp_dev, float b, float coef, long n, float* hat_dev);
+/* out = a*x + b*y (y may be NULL); out = x*y; clamp to [-1,1]. */
+int kdip_axpby(void* stream, const float* x_dev, float a, const float* y_dev, float b, long n, float* out_dev);
+int kdip_mul(void* stream, const float* x_dev, const float* y_dev, long n, float* out_dev);
+int kdip_clamp(void* stream, const float* x_dev, long n, float* out_dev);
+/* DPS: out[b] = zeta * x[b] / ||r[b]||_2 (per-sample norm; condition/condition.py:140-148). */
+int kdip_dps_normalize(void* stream, const float* x_dev, const float* r_dev, float zeta, int B, long per_sample,
+                       float* out_dev, float* norm_out_dev, double* tmp_dev);
+
+/* ------------------------------------------------------------- sampler updates (row A2)
+ * k_diffusion/sampling.py:46-48,118-135,159-184. */
+int kdip_sampler_add_noise(void* stream, const float* x_dev, const float* eps_dev, float s, long n, float* out_dev);
+int kdip_sampler_euler(void* stream, const float* x_dev, const float* denoised_dev, float sigma_hat, float dt, long n,
+                       float* out_dev);
+int kdip_sampler_heun(void* stream, const float* x_dev, const float* denoised_dev, const float* x2_dev,
+                      const float* denoised2_dev, float sigma_hat, float sigma_next, float dt, long n, float* out_dev);
+
+/* ------------------------------------------------------------------ low-level test hooks
+ * (exercised by tests/ to localise kernel bugs; NHWC tensors of the UNet storage dtype) */
+int kdip_test_conv(void* stream, int dtype, int ntaps, const float* x_nchw_dev, int B, int Cin, int H, int W,
+                   const float* w_host, const float* bias_host, int Cout, int transpose_flip, float* y_nchw_dev);
+int kdip_test_groupnorm(void* stream, int dtype, const float* x_nchw_dev, int B, int C, int H, int W,
+                        const float* gamma_host, const float* beta_host, const float* film_host, int silu,
+                        float* y_nchw_dev, const float* dy_nchw_dev, float* dx_nchw_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KDIP_H */

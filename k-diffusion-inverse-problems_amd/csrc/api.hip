@@ -1,0 +1,245 @@
+// C ABI of libkdip_hip (see include/kdip.h for the contract and reference citations).
+#include <vector>
+#include "../../include/kdip.h"
+#include "kernels.h"
+#include "fftops.h"
+#include "opctx.h"
+#include "unet.h"
+
+using namespace kdip;
+
+struct kdip_unet { UNet u; };
+struct kdip_op { OpCtx c; };
+
+#define API_CK(call) do { int _rc = (call); if (_rc) return _rc; } while (0)
+#define ST(s) ((hipStream_t)(s))
+
+extern "C" {
+
+const char* kdip_last_error(void) { return g_last_error.c_str(); }
+int kdip_version(void) { return 100; }
+
+// ------------------------------------------------------------------------------ UNet ----
+int kdip_unet_create(int device, int dtype, int image_size, int in_channels, int model_channels, int out_channels,
+                     int num_res_blocks, const int* attention_ds, int n_attention_ds, const int* channel_mult,
+                     int n_channel_mult, int num_head_channels, kdip_unet** out) {
+  KDIP_REQUIRE(out, "null output handle");
+  KDIP_REQUIRE(dtype == KDIP_F32 || dtype == KDIP_BF16, "dtype %d", dtype);
+  KDIP_REQUIRE(in_channels == 3 && out_channels <= 32, "in_channels must be 3, out_channels <= 32");
+  KDIP_REQUIRE(model_channels % 32 == 0, "model_channels must be a multiple of 32");
+  int ndev = 0;
+  KDIP_HIP_CHECK(hipGetDeviceCount(&ndev));
+  KDIP_REQUIRE(device >= 0 && device < ndev, "device %d out of range (%d visible)", device, ndev);
+  kdip_unet* h = new kdip_unet();
+  h->u.device = device;
+  h->u.dt = dtype == KDIP_BF16 ? DT_BF16 : DT_F32;
+  h->u.cfg.image_size = image_size; h->u.cfg.in_channels = in_channels; h->u.cfg.model_channels = model_channels;
+  h->u.cfg.out_channels = out_channels; h->u.cfg.num_res_blocks = num_res_blocks;
+  h->u.cfg.attention_ds.assign(attention_ds, attention_ds + n_attention_ds);
+  h->u.cfg.channel_mult.assign(channel_mult, channel_mult + n_channel_mult);
+  h->u.cfg.num_head_channels = num_head_channels;
+  int rc = h->u.build_plan();
+  if (rc) { delete h; return rc; }
+  *out = h;
+  return KDIP_OK;
+}
+void kdip_unet_destroy(kdip_unet* u) { delete u; }
+int kdip_unet_load(kdip_unet* u, const char* name, const float* data_host, const long* shape, int ndim) {
+  KDIP_REQUIRE(u && name && data_host && shape, "null argument");
+  return u->u.load(name, data_host, shape, ndim);
+}
+int kdip_unet_finalize(kdip_unet* u) { KDIP_REQUIRE(u, "null handle"); return u->u.finalize(); }
+int kdip_unet_forward(kdip_unet* u, void* stream, const float* x_dev, const float* t_dev, int B, float in_scale,
+                      float* out_dev, float* cov_out_dev, float* feature_dev) {
+  KDIP_REQUIRE(u && x_dev && t_dev && out_dev, "null argument");
+  KDIP_HIP_CHECK(hipSetDevice(u->u.device));
+  return u->u.run(ST(stream), x_dev, t_dev, B, in_scale, out_dev, cov_out_dev, feature_dev, 1);
+}
+int kdip_unet_vjp(kdip_unet* u, void* stream, const float* cot_dev, float* gx_dev) {
+  KDIP_REQUIRE(u && cot_dev && gx_dev, "null argument");
+  KDIP_HIP_CHECK(hipSetDevice(u->u.device));
+  return u->u.vjp(ST(stream), cot_dev, gx_dev);
+}
+long kdip_unet_workspace_bytes(kdip_unet* u, int B) {
+  if (!u) return -1;
+  if (B > 0 && u->u.finalized) { int rc = u->u.ensure_workspace(B); if (rc) return rc; }
+  return (long)(u->u.persist.cap + u->u.scratch.cap);
+}
+
+// -------------------------------------------------------------------------- operators ----
+int kdip_op_create(int device, int kind, int image_size, int scale_factor, float sigma_s, kdip_op** out) {
+  KDIP_REQUIRE(out, "null output handle");
+  KDIP_REQUIRE(kind >= 0 && kind <= 2, "operator kind %d", kind);
+  int ndev = 0;
+  KDIP_HIP_CHECK(hipGetDeviceCount(&ndev));
+  KDIP_REQUIRE(device >= 0 && device < ndev, "device %d out of range (%d visible)", device, ndev);
+  kdip_op* h = new kdip_op();
+  h->c.device = device; h->c.kind = kind; h->c.N = image_size; h->c.sf = kind == OP_SR ? scale_factor : 1;
+  h->c.sigma_s = sigma_s;
+  int rc = h->c.init();
+  if (rc) { delete h; return rc; }
+  *out = h;
+  return KDIP_OK;
+}
+void kdip_op_destroy(kdip_op* op) { delete op; }
+int kdip_op_set_psf(kdip_op* op, const float* psf_host, int kh, int kw) { KDIP_REQUIRE(op && psf_host, "null argument"); return op->c.set_psf(psf_host, kh, kw); }
+int kdip_op_set_separable(kdip_op* op, const float* kr, const float* kc, int taps) { KDIP_REQUIRE(op && kr && kc, "null argument"); return op->c.set_separable(kr, kc, taps); }
+int kdip_op_set_mask(kdip_op* op, const float* mask_host) { KDIP_REQUIRE(op && mask_host, "null argument"); return op->c.set_mask(mask_host); }
+int kdip_op_set_ortho(kdip_op* op, int t) { KDIP_REQUIRE(op, "null handle"); return op->c.set_ortho(t); }
+int kdip_op_get_otf(kdip_op* op, void* stream, float* otf_dev) {
+  KDIP_REQUIRE(op && otf_dev && op->c.FB, "no OTF");
+  KDIP_HIP_CHECK(hipMemcpyAsync(otf_dev, op->c.FB, sizeof(float2) * op->c.N * op->c.N, hipMemcpyDeviceToDevice, ST(stream)));
+  return KDIP_OK;
+}
+int kdip_op_apply(kdip_op* op, void* stream, const float* x_dev, int B, int adjoint, float* out_dev) {
+  KDIP_REQUIRE(op && x_dev && out_dev, "null argument");
+  OpCtx& c = op->c;
+  KDIP_HIP_CHECK(hipSetDevice(c.device));
+  const long nn = (long)c.N * c.N;
+  if (c.kind == OP_INPAINT) { KDIP_REQUIRE(c.mask, "no mask"); return mul_planes(ST(stream), x_dev, c.mask, 3L * B * nn, 3 * nn, out_dev); }
+  if (c.kind == OP_BLUR) return c.apply_A(ST(stream), x_dev, out_dev, B, adjoint);
+  if (adjoint) return c.sr_transpose(ST(stream), x_dev, out_dev, B);
+  API_CK(c.ensure_ws(B));
+  API_CK(c.apply_A(ST(stream), x_dev, c.rbuf[5], B, 0));
+  return strided_down(ST(stream), c.rbuf[5], c.N, c.sf, 3L * B, out_dev);
+}
+int kdip_op_solve(kdip_op* op, void* stream, const float* y_dev, const float* x0_dev, float var_scalar,
+                  const float* var_tensor_dev, int B, float* mat_dev, int* cg_iters_host, int* cg_info_host) {
+  KDIP_REQUIRE(op && y_dev && x0_dev && mat_dev, "null argument");
+  KDIP_HIP_CHECK(hipSetDevice(op->c.device));
+  return op->c.solve(ST(stream), y_dev, x0_dev, var_scalar, var_tensor_dev, B, mat_dev, cg_iters_host, cg_info_host);
+}
+int kdip_op_ortho(kdip_op* op, void* stream, const float* x_dev, int B, int inverse, float* out_dev) {
+  KDIP_REQUIRE(op && x_dev && out_dev, "null argument");
+  KDIP_HIP_CHECK(hipSetDevice(op->c.device));
+  return inverse ? op->c.ortho_inv(ST(stream), x_dev, out_dev, B) : op->c.ortho_fwd(ST(stream), x_dev, out_dev, B);
+}
+
+int kdip_gather(void* stream, const float* x, const long* idx, long nidx, long per, int B, float* out) { return gather_idx(ST(stream), x, idx, nidx, per, B, out); }
+int kdip_scatter(void* stream, const float* y, const long* idx, long nidx, long per, int B, float* out) { return scatter_idx(ST(stream), y, idx, nidx, per, B, out); }
+int kdip_mask_mul(void* stream, const float* x, const float* m, int B, long chw, float* out) { return mul_planes(ST(stream), x, m, (long)B * chw, chw, out); }
+int kdip_resize_axis(void* stream, const float* x, const float* w, const int* fov, int taps, int n_in, int n_out, int other,
+                     int axis, long planes, int adjoint, float* out) {
+  return adjoint ? resize_axis_adj(ST(stream), x, w, fov, taps, n_in, n_out, other, axis, planes, out)
+                 : resize_axis(ST(stream), x, w, fov, taps, n_in, n_out, other, axis, planes, out);
+}
+int kdip_blur_dense(void* stream, const float* x, const float* psf, int ks, int S, long planes, int adjoint, float* out) {
+  return blur_dense_circ(ST(stream), x, psf, ks, S, planes, adjoint, out);
+}
+int kdip_fft2(void* stream, int S, const float* in, int real_in, float* out, int real_out, long planes, int inverse, float* tmp) {
+  static float2* tw = nullptr;   // per-process twiddles on the current device
+  static int tw_dev = -1;
+  int dev = 0;
+  KDIP_HIP_CHECK(hipGetDevice(&dev));
+  if (!tw || tw_dev != dev) {
+    float2 host[128];
+    make_twiddles256(host);
+    KDIP_HIP_CHECK(hipMalloc((void**)&tw, sizeof(host)));
+    KDIP_HIP_CHECK(hipMemcpy(tw, host, sizeof(host), hipMemcpyHostToDevice));
+    tw_dev = dev;
+  }
+  return fft2(ST(stream), tw, S, in, real_in, (float2*)tmp, out, real_out, planes, inverse);
+}
+
+// --------------------------------------------------------------------------- guidance ----
+int kdip_x0_epilogue_v1(void* stream, const float* uo, const float* x, int B, long HW, const float* t7, float* x0,
+                        float* x0_raw, float* var) {
+  KDIP_REQUIRE(uo && x && t7 && x0, "null argument");
+  X0Params p;
+  p.c_in = t7[0]; p.sqrt_recip = t7[1]; p.sqrt_recipm1 = t7[2]; p.log_beta = t7[3]; p.log_post_var = t7[4];
+  p.post_var = t7[5]; p.coef1 = t7[6]; p.want_var = var ? 1 : 0;
+  return x0_epilogue_v1(ST(stream), uo, x, B, HW, p, x0, x0_raw, var);
+}
+int kdip_x0_epilogue_v2(void* stream, const float* uo, const float* co, const float* x, int B, long HW, float sigma,
+                        int want_var, float* x0, float* xv, float* tv) {
+  KDIP_REQUIRE(uo && x && x0 && (!want_var || (co && xv && tv)), "null argument");
+  return x0_epilogue_v2(ST(stream), uo, co, x, B, HW, sigma, want_var, x0, xv, tv);
+}
+int kdip_vjp_cotangent_v1(void* stream, const float* gh, const float* xraw, int B, long HW, float srm1, float* cot, float* graw) {
+  return vjp_cotangent_v1(ST(stream), gh, xraw, B, HW, srm1, cot, graw);
+}
+int kdip_vjp_cotangent_v2(void* stream, const float* gh, int B, long HW, float* cot) { return vjp_cotangent_v2(ST(stream), gh, B, HW, cot); }
+int kdip_guidance_combine(void* stream, const float* x0, const float* gd, float a, const float* uv, float b, float coef, long n, float* hat) {
+  return guidance_combine(ST(stream), x0, gd, a, uv, b, coef, n, hat);
+}
+int kdip_axpby(void* stream, const float* x, float a, const float* y, float b, long n, float* out) { return axpby(ST(stream), x, a, y, b, n, out); }
+int kdip_mul(void* stream, const float* x, const float* y, long n, float* out) { return mul_elem(ST(stream), x, y, n, out); }
+int kdip_clamp(void* stream, const float* x, long n, float* out) { return clamp_pm1(ST(stream), x, n, out); }
+int kdip_dps_normalize(void* stream, const float* x, const float* r, float zeta, int B, long per, float* out, float* nrm, double* tmp) {
+  API_CK(norm_per_sample(ST(stream), r, B, per, nrm, tmp));
+  return scale_per_sample_inv(ST(stream), x, nrm, zeta, B, per, out);
+}
+
+int kdip_sampler_add_noise(void* stream, const float* x, const float* eps, float s, long n, float* out) { return sampler_add_noise(ST(stream), x, eps, s, n, out); }
+int kdip_sampler_euler(void* stream, const float* x, const float* den, float sh, float dt, long n, float* out) { return sampler_euler(ST(stream), x, den, sh, dt, n, out); }
+int kdip_sampler_heun(void* stream, const float* x, const float* d1, const float* x2, const float* d2, float sh, float sn, float dt, long n, float* out) {
+  return sampler_heun(ST(stream), x, d1, x2, d2, sh, sn, dt, n, out);
+}
+
+// ------------------------------------------------------------------------- test hooks ----
+static inline int pad32i(int c) { return (c + 31) / 32 * 32; }
+
+int kdip_test_conv(void* stream, int dtype, int ntaps, const float* x_nchw, int B, int Cin, int H, int W, const float* w_host,
+                   const float* bias_host, int Cout, int transpose_flip, float* y_nchw) {
+  hipStream_t st = ST(stream);
+  DType dt = dtype == KDIP_BF16 ? DT_BF16 : DT_F32;
+  size_t es = dt == DT_BF16 ? 2 : 4;
+  // logical conv after optional transpose: Ci -> Co
+  const int Ci = transpose_flip ? Cout : Cin, Co = transpose_flip ? Cin : Cout;
+  const int cpad = pad32i(Ci);
+  std::vector<char> buf(packed_weight_bytes(dt, ntaps, cpad, Co));
+  pack_conv_weight(dt, w_host, Cout, Cin, ntaps, transpose_flip, cpad, buf.data());
+  void *wp = nullptr, *xin = nullptr; float *bias = nullptr, *y32 = nullptr;
+  KDIP_HIP_CHECK(hipMalloc(&wp, buf.size()));
+  KDIP_HIP_CHECK(hipMemcpy(wp, buf.data(), buf.size(), hipMemcpyHostToDevice));
+  if (bias_host) { KDIP_HIP_CHECK(hipMalloc((void**)&bias, sizeof(float) * Co)); KDIP_HIP_CHECK(hipMemcpy(bias, bias_host, sizeof(float) * Co, hipMemcpyHostToDevice)); }
+  KDIP_HIP_CHECK(hipMalloc(&xin, es * (size_t)B * H * W * cpad));
+  const int opad = pad32i(Co);
+  KDIP_HIP_CHECK(hipMalloc((void**)&y32, sizeof(float) * (size_t)B * H * W * opad));
+  int rc = nchw_to_nhwc(st, dt, x_nchw, B, Ci, H, W, 1.f, xin, cpad, cpad);
+  if (!rc) rc = conv_forward(st, dt, ntaps, xin, cpad, B, H, W, cpad, wp, bias, Co, y32, opad, nullptr, 0, 1, 1.f);
+  if (!rc) rc = nhwc_to_nchw_f32(st, y32, opad, B, Co, H, W, y_nchw);
+  hipError_t e = hipStreamSynchronize(st);
+  (void)hipFree(wp); (void)hipFree(xin); (void)hipFree(y32); if (bias) (void)hipFree(bias);
+  if (rc) return rc;
+  KDIP_HIP_CHECK(e);
+  return KDIP_OK;
+}
+
+int kdip_test_groupnorm(void* stream, int dtype, const float* x_nchw, int B, int C, int H, int W, const float* gamma_host,
+                        const float* beta_host, const float* film_host, int silu, float* y_nchw, const float* dy_nchw,
+                        float* dx_nchw) {
+  hipStream_t st = ST(stream);
+  DType dt = dtype == KDIP_BF16 ? DT_BF16 : DT_F32;
+  size_t es = dt == DT_BF16 ? 2 : 4;
+  const long HW = (long)H * W;
+  void *x = nullptr, *y = nullptr, *dy = nullptr, *dx = nullptr;
+  float *gamma, *beta, *film = nullptr, *coef, *mr; double *stats, *sums;
+  KDIP_HIP_CHECK(hipMalloc(&x, es * B * HW * C)); KDIP_HIP_CHECK(hipMalloc(&y, es * B * HW * C));
+  KDIP_HIP_CHECK(hipMalloc(&dy, es * B * HW * C)); KDIP_HIP_CHECK(hipMalloc(&dx, es * B * HW * C));
+  KDIP_HIP_CHECK(hipMalloc((void**)&gamma, 4 * C)); KDIP_HIP_CHECK(hipMalloc((void**)&beta, 4 * C));
+  KDIP_HIP_CHECK(hipMalloc((void**)&coef, 8 * B * C)); KDIP_HIP_CHECK(hipMalloc((void**)&mr, 4 * B * 64));
+  KDIP_HIP_CHECK(hipMalloc((void**)&stats, 8 * B * 64)); KDIP_HIP_CHECK(hipMalloc((void**)&sums, 8 * B * 64));
+  KDIP_HIP_CHECK(hipMemcpy(gamma, gamma_host, 4 * C, hipMemcpyHostToDevice));
+  KDIP_HIP_CHECK(hipMemcpy(beta, beta_host, 4 * C, hipMemcpyHostToDevice));
+  if (film_host) { KDIP_HIP_CHECK(hipMalloc((void**)&film, 8 * B * C)); KDIP_HIP_CHECK(hipMemcpy(film, film_host, 8 * B * C, hipMemcpyHostToDevice)); }
+  int rc = nchw_to_nhwc(st, dt, x_nchw, B, C, H, W, 1.f, x, C, C);
+  if (!rc) rc = gn_stats(st, dt, x, C, B, HW, C, stats);
+  if (!rc) rc = gn_coef(st, stats, gamma, beta, film, B, HW, C, 1e-5f, coef, mr);
+  if (!rc) rc = gn_apply(st, dt, x, C, coef, B, HW, C, silu, y, C);
+  if (!rc) rc = nhwc_T_to_nchw_f32(st, dt, y, C, B, C, H, W, y_nchw);
+  if (!rc && dy_nchw && dx_nchw) {
+    rc = nchw_to_nhwc(st, dt, dy_nchw, B, C, H, W, 1.f, dy, C, C);
+    if (!rc) rc = gn_bwd_stats(st, dt, x, C, dy, C, coef, mr, B, HW, C, silu, sums);
+    if (!rc) rc = gn_bwd_apply(st, dt, x, C, dy, C, coef, mr, sums, B, HW, C, silu, nullptr, 0, dx, C);
+    if (!rc) rc = nhwc_T_to_nchw_f32(st, dt, dx, C, B, C, H, W, dx_nchw);
+  }
+  hipError_t e = hipStreamSynchronize(st);
+  (void)hipFree(x); (void)hipFree(y); (void)hipFree(dy); (void)hipFree(dx); (void)hipFree(gamma); (void)hipFree(beta);
+  (void)hipFree(coef); (void)hipFree(mr); (void)hipFree(stats); (void)hipFree(sums); if (film) (void)hipFree(film);
+  if (rc) return rc;
+  KDIP_HIP_CHECK(e);
+  return KDIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,118 @@
+// Shared device/host helpers for libkdip_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include "../../include/kdip.h"
+
+namespace kdip {
+
+typedef unsigned short bf16_t;   // raw bfloat16 storage
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+enum DType { DT_F32 = 0, DT_BF16 = 1 };
+
+// status codes: the global KDIP_* enum of include/kdip.h (included above)
+
+extern thread_local std::string g_last_error;
+int set_error(int code, const char* fmt, ...);
+
+#define KDIP_HIP_CHECK(expr)                                                        \
+  do {                                                                              \
+    hipError_t _e = (expr);                                                         \
+    if (_e != hipSuccess)                                                           \
+      return kdip::set_error(KDIP_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #expr, \
+                             hipGetErrorString(_e));                                \
+  } while (0)
+
+#define KDIP_LAUNCH_CHECK() KDIP_HIP_CHECK(hipGetLastError())
+
+#define KDIP_REQUIRE(cond, ...)                                             \
+  do {                                                                      \
+    if (!(cond)) return kdip::set_error(KDIP_ERR_ARG, __VA_ARGS__);   \
+  } while (0)
+
+// ---- bf16 conversion (round-to-nearest-even), host+device ----
+__host__ __device__ inline float bf16_to_f32(bf16_t v) {
+  union { uint32_t u; float f; } c;
+  c.u = ((uint32_t)v) << 16;
+  return c.f;
+}
+__host__ __device__ inline bf16_t f32_to_bf16(float f) {
+  union { uint32_t u; float f; } c;
+  c.f = f;
+  uint32_t u = c.u;
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct TypeInfo;
+template <> struct TypeInfo<float> {
+  static constexpr int EPV = 4;   // elements per 16-byte vector
+  static constexpr DType dt = DT_F32;
+};
+template <> struct TypeInfo<bf16_t> {
+  static constexpr int EPV = 8;
+  static constexpr DType dt = DT_BF16;
+};
+
+__device__ inline float to_f32(float v) { return v; }
+__device__ inline float to_f32(bf16_t v) { return bf16_to_f32(v); }
+template <typename T> __device__ inline T from_f32(float v);
+template <> __device__ inline float from_f32<float>(float v) { return v; }
+template <> __device__ inline bf16_t from_f32<bf16_t>(float v) { return f32_to_bf16(v); }
+
+// 16-byte vector <-> float[EPV]
+template <typename T> __device__ inline void unpack16(const uint4& v, float* out);
+template <> __device__ inline void unpack16<float>(const uint4& v, float* out) {
+  out[0] = __uint_as_float(v.x); out[1] = __uint_as_float(v.y);
+  out[2] = __uint_as_float(v.z); out[3] = __uint_as_float(v.w);
+}
+template <> __device__ inline void unpack16<bf16_t>(const uint4& v, float* out) {
+  out[0] = __uint_as_float(v.x << 16); out[1] = __uint_as_float(v.x & 0xffff0000u);
+  out[2] = __uint_as_float(v.y << 16); out[3] = __uint_as_float(v.y & 0xffff0000u);
+  out[4] = __uint_as_float(v.z << 16); out[5] = __uint_as_float(v.z & 0xffff0000u);
+  out[6] = __uint_as_float(v.w << 16); out[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+template <typename T> __device__ inline uint4 pack16(const float* in);
+template <> __device__ inline uint4 pack16<float>(const float* in) {
+  return make_uint4(__float_as_uint(in[0]), __float_as_uint(in[1]), __float_as_uint(in[2]), __float_as_uint(in[3]));
+}
+template <> __device__ inline uint4 pack16<bf16_t>(const float* in) {
+  uint4 r;
+  r.x = (uint32_t)f32_to_bf16(in[0]) | ((uint32_t)f32_to_bf16(in[1]) << 16);
+  r.y = (uint32_t)f32_to_bf16(in[2]) | ((uint32_t)f32_to_bf16(in[3]) << 16);
+  r.z = (uint32_t)f32_to_bf16(in[4]) | ((uint32_t)f32_to_bf16(in[5]) << 16);
+  r.w = (uint32_t)f32_to_bf16(in[6]) | ((uint32_t)f32_to_bf16(in[7]) << 16);
+  return r;
+}
+
+__device__ inline float silu_f(float z) { return z / (1.f + __expf(-z)); }
+__device__ inline float silu_grad_f(float z) {
+  float s = 1.f / (1.f + __expf(-z));
+  return s * (1.f + z * (1.f - s));
+}
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace kdip

@@ -1,0 +1,311 @@
+// Implicit-GEMM convolution (3x3 pad 1 / 1x1) for NHWC activations on CDNA4 MFMA.
+//
+// Replaces nn.Conv2d / nn.Conv1d(k=1) / nn.Linear on the UNet path
+// (guided_diffusion/unet.py:182-222,293-295,472-477,484,614-618) and, with
+// flipped+transposed pre-packed weights, their input-gradients (the dgrad half of
+// torch.autograd.grad at condition/condition.py:172).
+//
+// GEMM view: M = B*H*W output pixels, N = Cout, K = taps*Cin.
+//   * A (activations): a (TH+2)x(TW+2) halo patch x 32 input channels is staged in
+//     LDS once per K-chunk and re-read by all 9 taps (9x reuse, +16 B pixel padding
+//     => conflict-free ds_read_b128).
+//   * B (weights): host-pre-packed in MFMA fragment order, so each lane fetches its
+//     16-byte B fragment straight from L2 into VGPRs (1 KiB contiguous per wave) --
+//     no LDS round trip, no barrier for weights.
+//   * bf16 storage  -> v_mfma_f32_32x32x16_bf16 (fp32 accumulate);
+//     f32 storage   -> v_mfma_f32_32x32x2_f32  (exact f32, parity mode).
+//   * Epilogue fuses bias, optional residual/accumulate tensor, and the cast.
+// 64-wide wavefronts; 4 waves/block; XCD-aware block remap keeps all N-tiles of an
+// M-tile on one XCD's L2.
+#include "common.h"
+#include "kernels.h"
+
+namespace kdip {
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  static constexpr int KSTEP = 16;  // channels per 16-byte-per-lane step
+  __device__ static inline void run(const uint4& a, const uint4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  static constexpr int KSTEP = 8;
+  __device__ static inline void run(const uint4& a, const uint4& b, f32x16& c) {
+    // lane half h holds channels h*4+j; MFMA j contracts the pair {j, 4+j}
+    f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], bf[j], c, 0, 0, 0);
+  }
+};
+
+struct ConvParams {
+  const void* x; long ldx;        // input NHWC, channel stride ldx (elements)
+  const void* wp;                 // packed weights
+  const float* bias;              // [Cout] or null
+  const void* res; long ldr;      // optional residual (same dtype as out), or null
+  void* y; long ldy;              // output
+  int B, H, W, Cin, Cout;         // Cin multiple of 32 (padded), Cout real
+  int ntilesN;                    // Cout padded / 32
+  int TH, TW, TB;                 // patch geometry (powers of two), TH*TW*TB == BM
+  int lgTW, lgTHW;
+  int tilesX, tilesY, mtiles;     // per-image tiles, total M tiles
+  int out_f32;                    // store fp32 regardless of T
+  float alpha;                    // output scale (applied before bias)
+};
+
+constexpr int KC = 32;            // input channels per LDS chunk
+
+template <typename T, int NTAPS, int WAVES_M, int WAVES_N, int MT, int NT>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(ConvParams p) {
+  constexpr int NTHREADS = WAVES_M * WAVES_N * 64;
+  constexpr int BM = WAVES_M * MT * 32;
+  constexpr int BN = WAVES_N * NT * 32;
+  constexpr int KSTEP = Mma<T>::KSTEP;
+  constexpr int KS = KC / KSTEP;                       // k-steps per chunk
+  constexpr int PIXB = KC * (int)sizeof(T) + 16;       // padded LDS pixel stride (bytes)
+  constexpr int VPP = KC * (int)sizeof(T) / 16;        // 16-byte vectors per pixel-chunk
+  constexpr int HALO = (NTAPS == 9) ? 1 : 0;
+  constexpr int MAXV = (sizeof(T) == 2) ? 4 : 8;       // staged vectors per thread (<=256 halo pixels)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  // ---- XCD-aware bijective remap: XCD k (= bid % 8) gets a contiguous logical range
+  const int nblk = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int nblkN = (p.ntilesN * 32 + BN - 1) / BN;
+  const int mtile = bid / nblkN, ntb = bid % nblkN;
+  // M tile -> (image group, patch origin)
+  const int tpi = p.tilesX * p.tilesY;                 // tiles per image (1 when TB>1)
+  const int b0 = (mtile / tpi) * p.TB;
+  const int trem = mtile % tpi;
+  const int y0 = (trem / p.tilesX) * p.TH, x0 = (trem % p.tilesX) * p.TW;
+  const int HW_ = p.TW + 2 * HALO, HH_ = p.TH + 2 * HALO;
+  const int npix = p.TB * HH_ * HW_;
+  const int abuf_bytes = npix * PIXB;
+
+  // ---- per-thread staging descriptors (constant across K chunks)
+  long goff[MAXV];
+  int loff[MAXV];
+  const T* xin = (const T*)p.x;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    int v = tid + i * NTHREADS;
+    int pix = v / VPP, sub = v % VPP;
+    goff[i] = -1;
+    loff[i] = -1;
+    if (pix < npix) {
+      int tb = pix / (HH_ * HW_), rr = pix % (HH_ * HW_);
+      int hy = rr / HW_, hx = rr % HW_;
+      int gy = y0 + hy - HALO, gx = x0 + hx - HALO, gb = b0 + tb;
+      loff[i] = pix * PIXB + sub * 16;
+      if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && gb < p.B)
+        goff[i] = (((long)gb * p.H + gy) * p.W + gx) * p.ldx + sub * (16 / (int)sizeof(T));
+    }
+  }
+  // ---- per-lane LDS base offsets of the MT m-tiles this wave owns (tap (0,0))
+  int abase[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int m = (wm * MT + mt) * 32 + (lane & 31);
+    int tb = m >> p.lgTHW, rr = m & ((1 << p.lgTHW) - 1);
+    int ty = rr >> p.lgTW, tx = rr & (p.TW - 1);
+    abase[mt] = ((tb * HH_ + ty) * HW_ + tx) * PIXB + (lane >> 5) * 16;
+  }
+  // ---- B fragment pointers
+  const int nt0 = ntb * (BN / 32) + wn * NT;           // first n-tile of this wave
+  const uint4* wp = (const uint4*)p.wp;
+  const long kstepsTotal = (long)(p.Cin / KSTEP);
+  auto bptr = [&](int tap, long kstep, int nt) -> const uint4* {
+    int ntile = nt0 + nt;
+    ntile = ntile < p.ntilesN ? ntile : p.ntilesN - 1;  // clamp (results discarded)
+    return wp + (((long)tap * kstepsTotal + kstep) * p.ntilesN + ntile) * 64 + lane;
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  const int nchunks = p.Cin / KC;
+  uint4 areg[MAXV];
+  auto stage_load = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      areg[i] = make_uint4(0, 0, 0, 0);
+      if (goff[i] >= 0) areg[i] = *(const uint4*)(xin + goff[i] + (long)c * KC);
+    }
+  };
+  auto stage_write = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+      if (loff[i] >= 0) *(uint4*)(smem + buf * abuf_bytes + loff[i]) = areg[i];
+  };
+
+  stage_load(0);
+  stage_write(0);
+  __syncthreads();
+
+  uint4 bcur[KS][NT], bnxt[KS][NT];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bcur[ks][nt] = *bptr(0, ks, nt);
+
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunks) stage_load(c + 1);
+    const unsigned char* abuf = smem + buf * abuf_bytes;
+#pragma unroll
+    for (int tap = 0; tap < NTAPS; ++tap) {
+      // prefetch next tap's (or next chunk's first) B fragments
+      {
+        int ntap = tap + 1;
+        long kbase = (long)c * KS;
+        if (ntap == NTAPS) { ntap = 0; kbase += KS; }
+        if (kbase < kstepsTotal) {
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bnxt[ks][nt] = *bptr(ntap, kbase + ks, nt);
+        }
+      }
+      const int toff = (NTAPS == 9) ? ((tap / 3) * HW_ + (tap % 3)) * PIXB : 0;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        uint4 a[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = *(const uint4*)(abuf + abase[mt] + toff + ks * 32);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) Mma<T>::run(a[mt], bcur[ks][nt], acc[mt][nt]);
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bcur[ks][nt] = bnxt[ks][nt];
+    }
+    if (c + 1 < nchunks) stage_write(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias + residual + cast, NHWC store (32 lanes = 32 consecutive channels)
+  const T* res = (const T*)p.res;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = (nt0 + nt) * 32 + (lane & 31);
+    const bool nok = n < p.Cout;
+    const float bv = (nok && p.bias) ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        int tb = m >> p.lgTHW, rr = m & ((1 << p.lgTHW) - 1);
+        int ty = rr >> p.lgTW, tx = rr & (p.TW - 1);
+        int gb = b0 + tb;
+        if (!nok || gb >= p.B) continue;
+        long pix = ((long)gb * p.H + (y0 + ty)) * p.W + (x0 + tx);
+        float v = acc[mt][nt][r] * p.alpha + bv;
+        if (res) v += to_f32(res[pix * p.ldr + n]);
+        if (p.out_f32) ((float*)p.y)[pix * p.ldy + n] = v;
+        else ((T*)p.y)[pix * p.ldy + n] = from_f32<T>(v);
+      }
+    }
+  }
+}
+
+template <typename T, int NTAPS, int WAVES_M, int WAVES_N, int MT, int NT>
+static int launch_cfg(ConvParams& p, hipStream_t st) {
+  constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32;
+  constexpr int PIXB = KC * (int)sizeof(T) + 16;
+  constexpr int HALO = (NTAPS == 9) ? 1 : 0;
+  int TW = p.W < 16 ? p.W : 16;
+  int TH = p.H < BM / TW ? p.H : BM / TW;
+  int TB = BM / (TH * TW);
+  auto ispow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+  if (!ispow2(TW) || !ispow2(TH) || p.H % TH || p.W % TW)
+    return set_error(KDIP_ERR_UNSUPPORTED, "conv: spatial size %dx%d not tileable", p.H, p.W);
+  if (TB > 1 && (TH != p.H || TW != p.W))
+    return set_error(KDIP_ERR_UNSUPPORTED, "conv: bad multi-image tile");
+  p.TH = TH; p.TW = TW; p.TB = TB;
+  p.lgTW = __builtin_ctz(TW); p.lgTHW = __builtin_ctz(TH * TW);
+  p.tilesX = p.W / TW; p.tilesY = p.H / TH;
+  p.mtiles = cdiv(p.B, TB) * p.tilesX * p.tilesY;
+  int npix = TB * (TH + 2 * HALO) * (TW + 2 * HALO);
+  if (npix > 256) return set_error(KDIP_ERR_UNSUPPORTED, "conv: halo patch too large (%d px)", npix);
+  size_t lds = (size_t)2 * npix * PIXB;
+  int nblkN = cdiv(p.ntilesN * 32, BN);
+  long grid = (long)p.mtiles * nblkN;
+  auto kern = conv_igemm_kernel<T, NTAPS, WAVES_M, WAVES_N, MT, NT>;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES_M * WAVES_N * 64), lds, st, p);
+  KDIP_LAUNCH_CHECK();
+  return KDIP_OK;
+}
+
+template <typename T, int NTAPS>
+static int launch_T(ConvParams& p, hipStream_t st) {
+  int npad = p.ntilesN * 32;
+  if (npad >= 128) return launch_cfg<T, NTAPS, 2, 2, 2, 2>(p, st);
+  if (npad >= 64) return launch_cfg<T, NTAPS, 2, 2, 2, 1>(p, st);
+  return launch_cfg<T, NTAPS, 4, 1, 1, 1>(p, st);
+}
+
+int conv_forward(hipStream_t st, DType dt, int ntaps, const void* x, long ldx, int B, int H, int W, int Cin,
+                 const void* wp, const float* bias, int Cout, void* y, long ldy, const void* res, long ldr,
+                 int out_f32, float alpha) {
+  KDIP_REQUIRE(Cin % KC == 0, "conv: Cin=%d must be a multiple of %d (pad the input)", Cin, KC);
+  KDIP_REQUIRE(ntaps == 9 || ntaps == 1, "conv: ntaps must be 9 or 1");
+  KDIP_REQUIRE((ldx * (dt == DT_BF16 ? 2 : 4)) % 16 == 0, "conv: input channel stride must be 16-byte aligned");
+  ConvParams p;
+  p.x = x; p.ldx = ldx; p.wp = wp; p.bias = bias; p.res = res; p.ldr = ldr; p.y = y; p.ldy = ldy;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.ntilesN = cdiv(Cout, 32);
+  p.out_f32 = out_f32; p.alpha = alpha;
+  if (dt == DT_BF16) return ntaps == 9 ? launch_T<bf16_t, 9>(p, st) : launch_T<bf16_t, 1>(p, st);
+  return ntaps == 9 ? launch_T<float, 9>(p, st) : launch_T<float, 1>(p, st);
+}
+
+// ---- host-side weight packing into MFMA B-fragment order --------------------------------
+// w: [Cout][Cin][kh][kw] fp32 (PyTorch layout), ntaps = kh*kw in {1, 9}.
+// transpose_flip: build the dgrad weight W'[ci][co][ky][kx] = W[co][ci][kh-1-ky][kw-1-kx].
+// Output element (tap, kstep, ntile, lane, e) = W[n][k][tap], n = ntile*32 + (lane&31),
+// k = kstep*KSTEP + (lane>>5)*EPL + e; zero outside [Cout) x [Cin).
+size_t packed_weight_bytes(DType dt, int ntaps, int Cin_pad, int Cout) {
+  size_t es = dt == DT_BF16 ? 2 : 4;
+  return (size_t)ntaps * Cin_pad * cdiv(Cout, 32) * 32 * es;
+}
+
+void pack_conv_weight(DType dt, const float* w, int Cout, int Cin, int ntaps, int transpose_flip, int Cin_pad_out,
+                      void* out) {
+  // logical conv after optional transpose: Co x Ci
+  const int Co = transpose_flip ? Cin : Cout, Ci = transpose_flip ? Cout : Cin;
+  const int kstep = dt == DT_BF16 ? 16 : 8, epl = dt == DT_BF16 ? 8 : 4;
+  const int ksteps = Cin_pad_out / kstep, ntiles = cdiv(Co, 32);
+  auto W = [&](int n, int k, int tap) -> float {
+    if (n >= Co || k >= Ci) return 0.f;
+    if (!transpose_flip) return w[((long)n * Cin + k) * ntaps + tap];
+    return w[((long)k * Cin + n) * ntaps + (ntaps - 1 - tap)];
+  };
+  long idx = 0;
+  for (int tap = 0; tap < ntaps; ++tap)
+    for (int ks = 0; ks < ksteps; ++ks)
+      for (int nt = 0; nt < ntiles; ++nt)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int e = 0; e < epl; ++e, ++idx) {
+            float v = W(nt * 32 + (lane & 31), ks * kstep + (lane >> 5) * epl + e, tap);
+            if (dt == DT_BF16) ((bf16_t*)out)[idx] = f32_to_bf16(v);
+            else ((float*)out)[idx] = v;
+          }
+}
+
+}  // namespace kdip

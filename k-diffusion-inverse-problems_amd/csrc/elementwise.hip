@@ -1,0 +1,288 @@
+// HBM-bound glue kernels of the UNet path (NHWC): 2x2 average pool / nearest x2 upsample
+// (Downsample/Upsample with use_conv=False inside up/down ResBlocks,
+// guided_diffusion/unet.py:101-108,133-137,190-197), channel concat/split copies
+// (th.cat at :662), residual adds, row softmax fwd/bwd (:352), SiLU, sinusoidal timestep
+// embedding (guided_diffusion/nn.py:103-121) and the NCHW<->NHWC boundary converts.
+// All are 16-byte-per-lane, channel-contiguous streaming kernels.
+#include "common.h"
+#include "kernels.h"
+
+namespace kdip {
+
+static inline int ew_grid(long n, int per = 256) {
+  long g = (n + per - 1) / per;
+  if (g < 1) g = 1;
+  if (g > 16384) g = 16384;
+  return (int)g;
+}
+
+// ------------------------------------------------------------------ pool / upsample ----
+template <typename T>
+__global__ void avgpool2_kernel(const T* __restrict__ x, long ldx, int B, int H, int W, int VP, T* __restrict__ y,
+                                long ldy, float scale) {
+  constexpr int EPV = TypeInfo<T>::EPV;
+  const int Ho = H / 2, Wo = W / 2;
+  long nvec = (long)B * Ho * Wo * VP;
+  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (long)gridDim.x * blockDim.x) {
+    int vi = (int)(v % VP);
+    long op = v / VP;
+    int ox = (int)(op % Wo);
+    long t = op / Wo;
+    int oy = (int)(t % Ho), b = (int)(t / Ho);
+    const T* p = x + (((long)b * H + 2 * oy) * W + 2 * ox) * ldx + (long)vi * EPV;
+    float a[EPV], c[EPV], d[EPV], e[EPV], o[EPV];
+    unpack16<T>(*(const uint4*)p, a);
+    unpack16<T>(*(const uint4*)(p + ldx), c);
+    unpack16<T>(*(const uint4*)(p + (long)W * ldx), d);
+    unpack16<T>(*(const uint4*)(p + (long)W * ldx + ldx), e);
+#pragma unroll
+    for (int i = 0; i < EPV; ++i) o[i] = (a[i] + c[i] + d[i] + e[i]) * scale;
+    *(uint4*)(y + op * ldy + (long)vi * EPV) = pack16<T>(o);
+  }
+}
+
+int avgpool2(hipStream_t st, DType dt, const void* x, long ldx, int B, int H, int W, int C, void* y, long ldy,
+             float scale) {
+  int VP = C / (dt == DT_BF16 ? 8 : 4);
+  long nvec = (long)B * (H / 2) * (W / 2) * VP;
+  if (dt == DT_BF16)
+    hipLaunchKernelGGL(avgpool2_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const bf16_t*)x, ldx, B, H, W, VP,
+                       (bf16_t*)y, ldy, scale);
+  else
+    hipLaunchKernelGGL(avgpool2_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const float*)x, ldx, B, H, W, VP,
+                       (float*)y, ldy, scale);
+  KDIP_LAUNCH_CHECK();
+  return KDIP_OK;
+}
+
+template <typename T>
+__global__ void upsample2_kernel(const T* __restrict__ x, long ldx, int B, int H, int W, int VP, T* __restrict__ y,
+                                 long ldy) {
+  constexpr int EPV = TypeInfo<T>::EPV;
+  const int Ho = H * 2, Wo = W * 2;
+  long nvec = (long)B * Ho * Wo * VP;
+  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (long)gridDim.x * blockDim.x) {
+    int vi = (int)(v % VP);
+    long op = v / VP;
+    int ox = (int)(op % Wo);
+    long t = op / Wo;
+    int oy = (int)(t % Ho), b = (int)(t / Ho);
+    uint4 val = *(const uint4*)(x + (((long)b * H + oy / 2) * W + ox / 2) * ldx + (long)vi * EPV);
+    *(uint4*)(y + op * ldy + (long)vi * EPV) = val;
+  }
+}
+
+int upsample2(hipStream_t st, DType dt, const void* x, long ldx, int B, int H, int W, int C, void* y, long ldy) {
+  int VP = C / (dt == DT_BF16 ? 8 : 4);
+  long nvec = (long)B * (H * 2) * (W * 2) * VP;
+  if (dt == DT_BF16)
+    hipLaunchKernelGGL(upsample2_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const bf16_t*)x, ldx, B, H, W, VP,
+                       (bf16_t*)y, ldy);
+  else
+    hipLaunchKernelGGL(upsample2_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const float*)x, ldx, B, H, W, VP,
+                       (float*)y, ldy);
+  KDIP_LAUNCH_CHECK();
+  return KDIP_OK;
+}
+
+// ------------------------------------------------------------------- copies / adds ----
+template <typename T>
+__global__ void copy_channels_kernel(const T* __restrict__ x, long ldx, long nvec, int VP, T* __restrict__ y, long ldy) {
+  constexpr int EPV = TypeInfo<T>::EPV;
+  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (long)gridDim.x * blockDim.x) {
+    long pix = v / VP;
+    int vi = (int)(v % VP);
+    *(uint4*)(y + pix * ldy + (long)vi * EPV) = *(const uint4*)(x + pix * ldx + (long)vi * EPV);
+  }
+}
+
+int copy_channels(hipStream_t st, DType dt, const void* x, long ldx, long npix, int C, void* y, long ldy) {
+  int VP = C / (dt == DT_BF16 ? 8 : 4);
+  long nvec = npix * VP;
+  if (dt == DT_BF16)
+    hipLaunchKernelGGL(copy_channels_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const bf16_t*)x, ldx, nvec, VP,
+                       (bf16_t*)y, ldy);
+  else
+    hipLaunchKernelGGL(copy_channels_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const float*)x, ldx, nvec, VP,
+                       (float*)y, ldy);
+  KDIP_LAUNCH_CHECK();
+  return KDIP_OK;
+}
+
+template <typename T>
+__global__ void add_channels_kernel(const T* __restrict__ a, long lda, const T* __restrict__ b, long ldb, long nvec,
+                                    int VP, T* __restrict__ y, long ldy) {
+  constexpr int EPV = TypeInfo<T>::EPV;
+  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (long)gridDim.x * blockDim.x) {
+    long pix = v / VP;
+    int vi = (int)(v % VP);
+    float fa[EPV], fb[EPV];
+    unpack16<T>(*(const uint4*)(a + pix * lda + (long)vi * EPV), fa);
+    unpack16<T>(*(const uint4*)(b + pix * ldb + (long)vi * EPV), fb);
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) fa[e] += fb[e];
+    *(uint4*)(y + pix * ldy + (long)vi * EPV) = pack16<T>(fa);
+  }
+}
+
+int add_channels(hipStream_t st, DType dt, const void* a, long lda, const void* b, long ldb, long npix, int C, void* y,
+                 long ldy) {
+  int VP = C / (dt == DT_BF16 ? 8 : 4);
+  long nvec = npix * VP;
+  if (dt == DT_BF16)
+    hipLaunchKernelGGL(add_channels_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const bf16_t*)a, lda,
+                       (const bf16_t*)b, ldb, nvec, VP, (bf16_t*)y, ldy);
+  else
+    hipLaunchKernelGGL(add_channels_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const float*)a, lda,
+                       (const float*)b, ldb, nvec, VP, (float*)y, ldy);
+  KDIP_LAUNCH_CHECK();
+  return KDIP_OK;
+}
+
+// ------------------------------------------------------------------------- softmax ----
+// One wavefront per row (cols <= 4096); fp32 math as in `th.softmax(weight.float())`.
+template <typename T>
+__global__ void softmax_rows_kernel(const float* __restrict__ s, long rows, int cols, T* __restrict__ p) {
+  long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* sr = s + row * cols;
+  float m = -INFINITY;
+  for (int c = lane; c < cols; c += 64) m = fmaxf(m, sr[c]);
+  m = wave_max(m);
+  float sum = 0.f;
+  for (int c = lane; c < cols; c += 64) sum += __expf(sr[c] - m);
+  sum = wave_sum(sum);
+  float inv = 1.f / sum;
+  for (int c = lane; c < cols; c += 64) p[row * cols + c] = from_f32<T>(__expf(sr[c] - m) * inv);
+}
+
+int softmax_rows(hipStream_t st, DType dt, const float* s, long rows, int cols, void* p) {
+  dim3 grid(cdiv(rows, 4));
+  if (dt == DT_BF16) hipLaunchKernelGGL(softmax_rows_kernel<bf16_t>, grid, dim3(256), 0, st, s, rows, cols, (bf16_t*)p);
+  else hipLaunchKernelGGL(softmax_rows_kernel<float>, grid, dim3(256), 0, st, s, rows, cols, (float*)p);
+  KDIP_LAUNCH_CHECK();
+  return KDIP_OK;
+}
+
+template <typename T>
+__global__ void softmax_bwd_rows_kernel(const T* __restrict__ p, const float* __restrict__ dp, long rows, int cols,
+                                        T* __restrict__ ds) {
+  long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const T* pr = p + row * cols;
+  const float* dr = dp + row * cols;
+  float dot = 0.f;
+  for (int c = lane; c < cols; c += 64) dot += to_f32(pr[c]) * dr[c];
+  dot = wave_sum(dot);
+  for (int c = lane; c < cols; c += 64) ds[row * cols + c] = from_f32<T>(to_f32(pr[c]) * (dr[c] - dot));
+}
+
+int softmax_bwd_rows(hipStream_t st, DType dt, const void* p, const float* dp, long rows, int cols, void* ds) {
+  dim3 grid(cdiv(rows, 4));
+  if (dt == DT_BF16)
+    hipLaunchKernelGGL(softmax_bwd_rows_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)p, dp, rows, cols, (bf16_t*)ds);
+  else
+    hipLaunchKernelGGL(softmax_bwd_rows_kernel<float>, grid, dim3(256), 0, st, (const float*)p, dp, rows, cols, (float*)ds);
+  KDIP_LAUNCH_CHECK();
+  return KDIP_OK;
+}
+
+// ----------------------------------------------------------------- small fp32 helpers ----
+__global__ void silu_f32_kernel(const float* x, long n, float* y) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float z = x[i];
+    y[i] = z / (1.f + expf(-z));
+  }
+}
+int silu_f32(hipStream_t st, const float* x, long n, float* y) {
+  hipLaunchKernelGGL(silu_f32_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x, n, y);
+  KDIP_LAUNCH_CHECK();
+  return KDIP_OK;
+}
+
+__global__ void timestep_embedding_kernel(const float* t, int B, int dim, float* out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int half = dim / 2;
+  if (i >= B * half) return;
+  int b = i / half, j = i % half;
+  float freq = expf(-logf(10000.f) * (float)j / (float)half);
+  float arg = t[b] * freq;
+  out[(long)b * dim + j] = cosf(arg);
+  out[(long)b * dim + half + j] = sinf(arg);
+}
+int timestep_embedding(hipStream_t st, const float* t, int B, int dim, float* out) {
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3(cdiv((long)B * dim / 2, 256)), dim3(256), 0, st, t, B, dim, out);
+  KDIP_LAUNCH_CHECK();
+  return KDIP_OK;
+}
+
+template <typename T>
+__global__ void f32_to_T_kernel(const float* x, long n, T* y) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = from_f32<T>(x[i]);
+}
+int f32_to_T(hipStream_t st, DType dt, const float* x, long n, void* y) {
+  if (dt == DT_BF16) hipLaunchKernelGGL(f32_to_T_kernel<bf16_t>, dim3(ew_grid(n)), dim3(256), 0, st, x, n, (bf16_t*)y);
+  else hipLaunchKernelGGL(f32_to_T_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, st, x, n, (float*)y);
+  KDIP_LAUNCH_CHECK();
+  return KDIP_OK;
+}
+template <typename T>
+__global__ void T_to_f32_kernel(const T* x, long n, float* y) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = to_f32(x[i]);
+}
+int T_to_f32(hipStream_t st, DType dt, const void* x, long n, float* y) {
+  if (dt == DT_BF16) hipLaunchKernelGGL(T_to_f32_kernel<bf16_t>, dim3(ew_grid(n)), dim3(256), 0, st, (const bf16_t*)x, n, y);
+  else hipLaunchKernelGGL(T_to_f32_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, st, (const float*)x, n, y);
+  KDIP_LAUNCH_CHECK();
+  return KDIP_OK;
+}
+
+// NCHW fp32 -> NHWC T with channel padding (pixel-major threads; C is tiny: 3)
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, int B, int C, long HW, float scale, T* __restrict__ y,
+                                    long ld, int Cpad) {
+  long n = (long)B * HW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    long b = i / HW, p = i % HW;
+    T* o = y + i * ld;
+    for (int c = 0; c < Cpad; ++c) o[c] = from_f32<T>(c < C ? x[(b * C + c) * HW + p] * scale : 0.f);
+  }
+}
+int nchw_to_nhwc(hipStream_t st, DType dt, const float* x, int B, int C, int H, int W, float scale, void* y, long ld,
+                 int Cpad) {
+  long HW = (long)H * W;
+  if (dt == DT_BF16)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(ew_grid(B * HW)), dim3(256), 0, st, x, B, C, HW, scale, (bf16_t*)y, ld, Cpad);
+  else
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(ew_grid(B * HW)), dim3(256), 0, st, x, B, C, HW, scale, (float*)y, ld, Cpad);
+  KDIP_LAUNCH_CHECK();
+  return KDIP_OK;
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ x, long ld, int B, int C, long HW, float* __restrict__ y) {
+  long n = (long)B * HW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    long b = i / HW, p = i % HW;
+    for (int c = 0; c < C; ++c) y[(b * C + c) * HW + p] = to_f32(x[i * ld + c]);
+  }
+}
+int nhwc_to_nchw_f32(hipStream_t st, const float* x, long ld, int B, int C, int H, int W, float* y) {
+  long HW = (long)H * W;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(ew_grid(B * HW)), dim3(256), 0, st, x, ld, B, C, HW, y);
+  KDIP_LAUNCH_CHECK();
+  return KDIP_OK;
+}
+int nhwc_T_to_nchw_f32(hipStream_t st, DType dt, const void* x, long ld, int B, int C, int H, int W, float* y) {
+  long HW = (long)H * W;
+  if (dt == DT_BF16)
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(ew_grid(B * HW)), dim3(256), 0, st, (const bf16_t*)x, ld, B, C, HW, y);
+  else
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(ew_grid(B * HW)), dim3(256), 0, st, (const float*)x, ld, B, C, HW, y);
+  KDIP_LAUNCH_CHECK();
+  return KDIP_OK;
+}
+
+}  // namespace kdip

@@ -1,0 +1,63 @@
+// Internal C++ launch API shared by the translation units of libkdip_hip.
+#pragma once
+#include "common.h"
+
+namespace kdip {
+
+// ---- conv.hip ---------------------------------------------------------------------------
+int conv_forward(hipStream_t st, DType dt, int ntaps, const void* x, long ldx, int B, int H, int W, int Cin,
+                 const void* wp, const float* bias, int Cout, void* y, long ldy, const void* res, long ldr,
+                 int out_f32, float alpha);
+size_t packed_weight_bytes(DType dt, int ntaps, int Cin_pad, int Cout);
+void pack_conv_weight(DType dt, const float* w, int Cout, int Cin, int ntaps, int transpose_flip, int Cin_pad_out,
+                      void* out);
+
+// ---- gemm.hip: strided batched GEMM  C[b] = alpha * A[b] (MxK) * B[b] (KxN) ----------------
+// element strides; batch index b = b1*nb2 + b2 with separate strides per level.
+struct BGemm {
+  const void* A; long sam, sak, sab1, sab2;
+  const void* Bm; long sbk, sbn, sbb1, sbb2;
+  void* C; long scm, scn, scb1, scb2;
+  int M, N, K, nb1, nb2;
+  float alpha;
+  int c_f32;       // C stored as fp32 regardless of dt
+  int a_f32;       // A stored as fp32 regardless of dt
+};
+int bgemm(hipStream_t st, DType dt, const BGemm& g);
+
+// ---- norm.hip ---------------------------------------------------------------------------
+// GroupNorm(32) over NHWC [B, HW, C] (ld = channel stride). stats: double [B][32][2] (sum, sumsq), zeroed by callee.
+int gn_stats(hipStream_t st, DType dt, const void* x, long ldx, int B, long HW, int C, double* stats);
+// coef[B][C][2] = (a, b) with y = a*x + b  [then SiLU]; a = rstd*gamma*(1+scale), b = (beta - mean*rstd*gamma)*(1+scale)+shift
+// film: [B][2C] fp32 (scale | shift) or null.  Also writes mr[B][32][2] = (mean, rstd) fp32.
+int gn_coef(hipStream_t st, const double* stats, const float* gamma, const float* beta, const float* film,
+            int B, long HW, int C, float eps, float* coef, float* mr);
+int gn_apply(hipStream_t st, DType dt, const void* x, long ldx, const float* coef, int B, long HW, int C, int silu,
+             void* y, long ldy);
+// backward: dy wrt apply output -> dx (+ optional addend), two passes.
+int gn_bwd_stats(hipStream_t st, DType dt, const void* x, long ldx, const void* dy, long lddy, const float* coef,
+                 const float* mr, int B, long HW, int C, int silu, double* sums);
+int gn_bwd_apply(hipStream_t st, DType dt, const void* x, long ldx, const void* dy, long lddy, const float* coef,
+                 const float* mr, const double* sums, int B, long HW, int C, int silu, const void* addend, long lda,
+                 void* dx, long lddx);
+
+// ---- elementwise.hip --------------------------------------------------------------------
+int avgpool2(hipStream_t st, DType dt, const void* x, long ldx, int B, int H, int W, int C, void* y, long ldy, float scale);
+int upsample2(hipStream_t st, DType dt, const void* x, long ldx, int B, int H, int W, int C, void* y, long ldy);
+// sum of each 2x2 block (adjoint of nearest upsample): implemented as avgpool2 with scale 4.
+int copy_channels(hipStream_t st, DType dt, const void* x, long ldx, long npix, int C, void* y, long ldy);
+int add_channels(hipStream_t st, DType dt, const void* a, long lda, const void* b, long ldb, long npix, int C,
+                 void* y, long ldy);
+int softmax_rows(hipStream_t st, DType dt, const float* s, long rows, int cols, void* p);
+// dS = P * (dP - rowsum(dP*P)); dP fp32 in, P dtype T, dS out dtype T
+int softmax_bwd_rows(hipStream_t st, DType dt, const void* p, const float* dp, long rows, int cols, void* ds);
+int silu_f32(hipStream_t st, const float* x, long n, float* y);
+int timestep_embedding(hipStream_t st, const float* t, int B, int dim, float* out);
+int f32_to_T(hipStream_t st, DType dt, const float* x, long n, void* y);
+int T_to_f32(hipStream_t st, DType dt, const void* x, long n, float* y);
+// NCHW fp32 [B,C,H,W] * scale -> NHWC T [B,H,W,ld] (channels >= C zero-filled up to Cpad)
+int nchw_to_nhwc(hipStream_t st, DType dt, const float* x, int B, int C, int H, int W, float scale, void* y, long ld, int Cpad);
+int nhwc_to_nchw_f32(hipStream_t st, const float* x, long ld, int B, int C, int H, int W, float* y);
+int nhwc_T_to_nchw_f32(hipStream_t st, DType dt, const void* x, long ld, int B, int C, int H, int W, float* y);
+
+}  // namespace kdip

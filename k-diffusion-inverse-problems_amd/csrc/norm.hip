@@ -1,0 +1,293 @@
+// GroupNorm(32) forward / backward for NHWC activations, fused with FiLM and SiLU.
+//
+// Replaces GroupNorm32 (fp32 statistics, guided_diffusion/nn.py:17-19,93-100) +
+// nn.SiLU + the scale-shift FiLM `GN(h)*(1+scale)+shift` (guided_diffusion/unet.py:183-184,
+// 207-208,249-253) and their backward.  All kernels are HBM-bound streaming passes:
+// 16-byte loads, every lane on consecutive channels of a pixel (NHWC => fully coalesced),
+// statistics accumulated fp32 per thread, combined in fp64 (LDS + one global atomic per
+// group per block) so the E[x^2]-mean^2 form has no visible cancellation.
+#include "common.h"
+#include "kernels.h"
+
+namespace kdip {
+
+struct GnGeom {
+  int VP;        // 16-byte vectors per pixel
+  int lanes;     // pixel lanes per block
+  int nthreads;  // block size
+  int cpg;       // channels per group
+};
+
+template <typename T> static GnGeom gn_geom(int C) {
+  GnGeom g;
+  g.VP = C / TypeInfo<T>::EPV;
+  g.nthreads = g.VP <= 256 ? 256 : (g.VP <= 512 ? 512 : 1024);
+  g.lanes = g.nthreads / g.VP;
+  g.cpg = C / 32;
+  return g;
+}
+
+// ---------------------------------------------------------------- forward statistics ----
+template <typename T>
+__global__ void gn_stats_kernel(const T* __restrict__ x, long ldx, long HW, int C, int VP, int lanes, int cpg,
+                                long chunk, double* __restrict__ stats) {
+  constexpr int EPV = TypeInfo<T>::EPV;
+  __shared__ double sh[32][2];
+  const int tid = threadIdx.x, b = blockIdx.y;
+  if (tid < 64) sh[tid >> 1][tid & 1] = 0.0;
+  __syncthreads();
+  const int vi = tid % VP, pl = tid / VP;
+  if (pl < lanes) {
+    float s[EPV], ss[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) s[e] = ss[e] = 0.f;
+    long p0 = (long)blockIdx.x * chunk, p1 = p0 + chunk < HW ? p0 + chunk : HW;
+    const T* base = x + ((long)b * HW) * ldx + (long)vi * EPV;
+    for (long p = p0 + pl; p < p1; p += lanes) {
+      uint4 v = *(const uint4*)(base + p * ldx);
+      float f[EPV];
+      unpack16<T>(v, f);
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) { s[e] += f[e]; ss[e] += f[e] * f[e]; }
+    }
+    if (cpg % EPV == 0) {
+      float a = 0.f, q = 0.f;
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) { a += s[e]; q += ss[e]; }
+      int g = (vi * EPV) / cpg;
+      atomicAdd(&sh[g][0], (double)a);
+      atomicAdd(&sh[g][1], (double)q);
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) {
+        int g = (vi * EPV + e) / cpg;
+        atomicAdd(&sh[g][0], (double)s[e]);
+        atomicAdd(&sh[g][1], (double)ss[e]);
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < 64) atomicAdd(&stats[((long)b * 32 + (tid >> 1)) * 2 + (tid & 1)], sh[tid >> 1][tid & 1]);
+}
+
+static long pick_chunk(long HW, int B) {
+  // aim for >= ~1024 blocks, at least 256 pixels per block
+  long want = (1024 + B - 1) / B;
+  long chunk = (HW + want - 1) / want;
+  if (chunk < 256) chunk = 256;
+  return chunk;
+}
+
+int gn_stats(hipStream_t st, DType dt, const void* x, long ldx, int B, long HW, int C, double* stats) {
+  KDIP_REQUIRE(C % 32 == 0, "groupnorm: C=%d not a multiple of 32", C);
+  KDIP_HIP_CHECK(hipMemsetAsync(stats, 0, sizeof(double) * B * 64, st));
+  long chunk = pick_chunk(HW, B);
+  dim3 grid(cdiv(HW, chunk), B);
+  if (dt == DT_BF16) {
+    KDIP_REQUIRE(C % 8 == 0 && C / 8 <= 1024, "groupnorm: unsupported C=%d", C);
+    GnGeom g = gn_geom<bf16_t>(C);
+    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(g.nthreads), 0, st, (const bf16_t*)x, ldx, HW, C, g.VP,
+                       g.lanes, g.cpg, chunk, stats);
+  } else {
+    KDIP_REQUIRE(C / 4 <= 1024, "groupnorm: unsupported C=%d", C);
+    GnGeom g = gn_geom<float>(C);
+    hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(g.nthreads), 0, st, (const float*)x, ldx, HW, C, g.VP,
+                       g.lanes, g.cpg, chunk, stats);
+  }
+  KDIP_LAUNCH_CHECK();
+  return KDIP_OK;
+}
+
+// ------------------------------------------------------------------------- coefficients ----
+__global__ void gn_coef_kernel(const double* __restrict__ stats, const float* __restrict__ gamma,
+                               const float* __restrict__ beta, const float* __restrict__ film, int B, long HW, int C,
+                               float eps, float* __restrict__ coef, float* __restrict__ mr) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  int b = i / C, c = i % C, cpg = C / 32, g = c / cpg;
+  double n = (double)HW * cpg;
+  double mean = stats[((long)b * 32 + g) * 2] / n;
+  double var = stats[((long)b * 32 + g) * 2 + 1] / n - mean * mean;
+  if (var < 0) var = 0;
+  float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  float m = (float)mean;
+  float a = rstd * gamma[c];
+  float bb = beta[c] - m * a;
+  if (film) {
+    float sc = 1.f + film[(long)b * 2 * C + c], sh = film[(long)b * 2 * C + C + c];
+    a *= sc;
+    bb = bb * sc + sh;
+  }
+  coef[(long)i * 2] = a;
+  coef[(long)i * 2 + 1] = bb;
+  if (c % cpg == 0) { mr[((long)b * 32 + g) * 2] = m; mr[((long)b * 32 + g) * 2 + 1] = rstd; }
+}
+
+int gn_coef(hipStream_t st, const double* stats, const float* gamma, const float* beta, const float* film, int B,
+            long HW, int C, float eps, float* coef, float* mr) {
+  hipLaunchKernelGGL(gn_coef_kernel, dim3(cdiv((long)B * C, 256)), dim3(256), 0, st, stats, gamma, beta, film, B, HW, C,
+                     eps, coef, mr);
+  KDIP_LAUNCH_CHECK();
+  return KDIP_OK;
+}
+
+// ------------------------------------------------------------------------------ apply ----
+template <typename T>
+__global__ void gn_apply_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ coef, long HW, int C,
+                                int VP, long nvec, int silu, T* __restrict__ y, long ldy) {
+  constexpr int EPV = TypeInfo<T>::EPV;
+  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (long)gridDim.x * blockDim.x) {
+    long pix = v / VP;
+    int vi = (int)(v % VP);
+    int b = (int)(pix / HW);
+    uint4 xv = *(const uint4*)(x + pix * ldx + (long)vi * EPV);
+    float f[EPV];
+    unpack16<T>(xv, f);
+    const float4* cp = (const float4*)(coef + ((long)b * C + (long)vi * EPV) * 2);
+#pragma unroll
+    for (int e = 0; e < EPV; e += 2) {
+      float4 c4 = cp[e >> 1];
+      float z0 = c4.x * f[e] + c4.y, z1 = c4.z * f[e + 1] + c4.w;
+      f[e] = silu ? silu_f(z0) : z0;
+      f[e + 1] = silu ? silu_f(z1) : z1;
+    }
+    *(uint4*)(y + pix * ldy + (long)vi * EPV) = pack16<T>(f);
+  }
+}
+
+int gn_apply(hipStream_t st, DType dt, const void* x, long ldx, const float* coef, int B, long HW, int C, int silu,
+             void* y, long ldy) {
+  int EPV = dt == DT_BF16 ? 8 : 4;
+  int VP = C / EPV;
+  long nvec = (long)B * HW * VP;
+  int grid = (int)(nvec / 256 < 1 ? 1 : (nvec / 256 > 8192 ? 8192 : nvec / 256));
+  if (dt == DT_BF16)
+    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, ldx, coef, HW, C, VP,
+                       nvec, silu, (bf16_t*)y, ldy);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, ldx, coef, HW, C, VP,
+                       nvec, silu, (float*)y, ldy);
+  KDIP_LAUNCH_CHECK();
+  return KDIP_OK;
+}
+
+// --------------------------------------------------------------------------- backward ----
+// z = a*x + b, y = silu(z) | z.  dz = dy*silu'(z) | dy.  xh = (x-mean)*rstd.
+// T1 = sum_g a*dz, T2 = sum_g a*dz*xh;   dx = a*dz - T1/N - xh*T2/N   (N = HW*cpg)
+template <typename T>
+__global__ void gn_bwd_stats_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy, long lddy,
+                                    const float* __restrict__ coef, const float* __restrict__ mr, long HW, int C,
+                                    int VP, int lanes, int cpg, long chunk, int silu, double* __restrict__ sums) {
+  constexpr int EPV = TypeInfo<T>::EPV;
+  __shared__ double sh[32][2];
+  const int tid = threadIdx.x, b = blockIdx.y;
+  if (tid < 64) sh[tid >> 1][tid & 1] = 0.0;
+  __syncthreads();
+  const int vi = tid % VP, pl = tid / VP;
+  if (pl < lanes) {
+    float t1[EPV], t2[EPV], a[EPV], bb[EPV], mean[EPV], rstd[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+      int c = vi * EPV + e, g = c / cpg;
+      t1[e] = t2[e] = 0.f;
+      a[e] = coef[((long)b * C + c) * 2];
+      bb[e] = coef[((long)b * C + c) * 2 + 1];
+      mean[e] = mr[((long)b * 32 + g) * 2];
+      rstd[e] = mr[((long)b * 32 + g) * 2 + 1];
+    }
+    long p0 = (long)blockIdx.x * chunk, p1 = p0 + chunk < HW ? p0 + chunk : HW;
+    const T* xb = x + ((long)b * HW) * ldx + (long)vi * EPV;
+    const T* db = dy + ((long)b * HW) * lddy + (long)vi * EPV;
+    for (long p = p0 + pl; p < p1; p += lanes) {
+      float fx[EPV], fd[EPV];
+      unpack16<T>(*(const uint4*)(xb + p * ldx), fx);
+      unpack16<T>(*(const uint4*)(db + p * lddy), fd);
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) {
+        float z = a[e] * fx[e] + bb[e];
+        float dz = silu ? fd[e] * silu_grad_f(z) : fd[e];
+        float adz = a[e] * dz;
+        t1[e] += adz;
+        t2[e] += adz * (fx[e] - mean[e]) * rstd[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+      int g = (vi * EPV + e) / cpg;
+      atomicAdd(&sh[g][0], (double)t1[e]);
+      atomicAdd(&sh[g][1], (double)t2[e]);
+    }
+  }
+  __syncthreads();
+  if (tid < 64) atomicAdd(&sums[((long)b * 32 + (tid >> 1)) * 2 + (tid & 1)], sh[tid >> 1][tid & 1]);
+}
+
+int gn_bwd_stats(hipStream_t st, DType dt, const void* x, long ldx, const void* dy, long lddy, const float* coef,
+                 const float* mr, int B, long HW, int C, int silu, double* sums) {
+  KDIP_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * B * 64, st));
+  long chunk = pick_chunk(HW, B);
+  dim3 grid(cdiv(HW, chunk), B);
+  if (dt == DT_BF16) {
+    GnGeom g = gn_geom<bf16_t>(C);
+    hipLaunchKernelGGL(gn_bwd_stats_kernel<bf16_t>, grid, dim3(g.nthreads), 0, st, (const bf16_t*)x, ldx,
+                       (const bf16_t*)dy, lddy, coef, mr, HW, C, g.VP, g.lanes, g.cpg, chunk, silu, sums);
+  } else {
+    GnGeom g = gn_geom<float>(C);
+    hipLaunchKernelGGL(gn_bwd_stats_kernel<float>, grid, dim3(g.nthreads), 0, st, (const float*)x, ldx,
+                       (const float*)dy, lddy, coef, mr, HW, C, g.VP, g.lanes, g.cpg, chunk, silu, sums);
+  }
+  KDIP_LAUNCH_CHECK();
+  return KDIP_OK;
+}
+
+template <typename T>
+__global__ void gn_bwd_apply_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy, long lddy,
+                                    const float* __restrict__ coef, const float* __restrict__ mr,
+                                    const double* __restrict__ sums, long HW, int C, int VP, int cpg, long nvec,
+                                    int silu, const T* __restrict__ addend, long lda, T* __restrict__ dx, long lddx) {
+  constexpr int EPV = TypeInfo<T>::EPV;
+  const float invN = 1.f / ((float)HW * (float)cpg);
+  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (long)gridDim.x * blockDim.x) {
+    long pix = v / VP;
+    int vi = (int)(v % VP);
+    int b = (int)(pix / HW);
+    float fx[EPV], fd[EPV], fa[EPV], out[EPV];
+    unpack16<T>(*(const uint4*)(x + pix * ldx + (long)vi * EPV), fx);
+    unpack16<T>(*(const uint4*)(dy + pix * lddy + (long)vi * EPV), fd);
+    if (addend) unpack16<T>(*(const uint4*)(addend + pix * lda + (long)vi * EPV), fa);
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+      int c = vi * EPV + e, g = c / cpg;
+      float a = coef[((long)b * C + c) * 2], bb = coef[((long)b * C + c) * 2 + 1];
+      float mean = mr[((long)b * 32 + g) * 2], rstd = mr[((long)b * 32 + g) * 2 + 1];
+      float t1 = (float)sums[((long)b * 32 + g) * 2] * invN, t2 = (float)sums[((long)b * 32 + g) * 2 + 1] * invN;
+      float z = a * fx[e] + bb;
+      float dz = silu ? fd[e] * silu_grad_f(z) : fd[e];
+      float xh = (fx[e] - mean) * rstd;
+      float r = a * dz - (t1 + xh * t2);
+      out[e] = addend ? r + fa[e] : r;
+    }
+    *(uint4*)(dx + pix * lddx + (long)vi * EPV) = pack16<T>(out);
+  }
+}
+
+int gn_bwd_apply(hipStream_t st, DType dt, const void* x, long ldx, const void* dy, long lddy, const float* coef,
+                 const float* mr, const double* sums, int B, long HW, int C, int silu, const void* addend, long lda,
+                 void* dx, long lddx) {
+  int EPV = dt == DT_BF16 ? 8 : 4;
+  int VP = C / EPV;
+  long nvec = (long)B * HW * VP;
+  int grid = (int)(nvec / 256 < 1 ? 1 : (nvec / 256 > 8192 ? 8192 : nvec / 256));
+  if (dt == DT_BF16)
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, ldx,
+                       (const bf16_t*)dy, lddy, coef, mr, sums, HW, C, VP, C / 32, nvec, silu, (const bf16_t*)addend,
+                       lda, (bf16_t*)dx, lddx);
+  else
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, ldx,
+                       (const float*)dy, lddy, coef, mr, sums, HW, C, VP, C / 32, nvec, silu, (const float*)addend,
+                       lda, (float*)dx, lddx);
+  KDIP_LAUNCH_CHECK();
+  return KDIP_OK;
+}
+
+}  // namespace kdip

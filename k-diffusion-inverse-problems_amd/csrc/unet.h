@@ -1,0 +1,93 @@
+// ADM UNet executor: plan + packed weights + forward (with activation stash) + input-VJP.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+#include "common.h"
+
+namespace kdip {
+
+struct UNetConfig {
+  int image_size, in_channels, model_channels, out_channels, num_res_blocks;
+  std::vector<int> attention_ds;     // downsample rates with attention
+  std::vector<int> channel_mult;
+  int num_head_channels;
+};
+
+struct ConvW {
+  int cin = 0, cout = 0, cin_pad = 0, ntaps = 0;
+  void* wf = nullptr;      // packed forward weights (device)
+  void* wb = nullptr;      // packed dgrad weights (device): cin' = cout (padded to 32), cout' = cin
+  int cin_pad_b = 0;       // padded K of the dgrad conv (= pad32(cout))
+  float* bias = nullptr;   // device fp32 [cout]
+};
+struct LinW { int in = 0, out = 0; float* w = nullptr; float* b = nullptr; };   // fp32 [out][in]
+struct GnW { int C = 0; float* gamma = nullptr; float* beta = nullptr; };
+
+struct Saved {            // per-layer stash for the VJP
+  const void* x = nullptr; long ldx = 0;
+  void* h2 = nullptr;
+  float *coef1 = nullptr, *mr1 = nullptr, *coef2 = nullptr, *mr2 = nullptr;
+  void* qkv = nullptr; void* P = nullptr;
+  int B = 0, H = 0, W = 0;
+};
+
+struct Layer {
+  int kind;                // 0 conv, 1 res, 2 attn
+  std::string prefix;
+  int cin, cout, mode;     // mode: 0 none, 1 down, 2 up
+  ConvW conv;              // kind 0
+  GnW n1, n2; ConvW c1, c2, skip; LinW emb; bool has_skip = false;   // kind 1
+  GnW norm; ConvW qkv, proj; int heads = 0;                          // kind 2
+  Saved sv;
+};
+
+struct Arena {
+  char* base = nullptr; size_t cap = 0, off = 0, peak = 0;
+  void* alloc(size_t bytes) {
+    size_t a = (off + 255) & ~(size_t)255;
+    off = a + bytes;
+    if (off > peak) peak = off;
+    return base ? (void*)(base + a) : (void*)(uintptr_t)(a + 4096);   // dry run: fake non-null address
+  }
+  void reset() { off = 0; }
+};
+
+struct UNet {
+  UNetConfig cfg;
+  DType dt;
+  int device = 0;
+  std::vector<std::vector<Layer>> inp, out;
+  std::vector<Layer> mid;
+  int final_ch = 0;
+  LinW te0, te2;
+  GnW out_norm; ConvW out_conv; ConvW cov_conv; bool has_cov = false;
+  std::map<std::string, std::vector<float>> raw;      // host fp32 parameters by reference state_dict name
+  std::map<std::string, std::vector<long>> raw_shape;
+  bool finalized = false;
+  std::vector<void*> dev_allocs;
+
+  Arena persist, scratch;
+  int ws_B = 0;
+  bool dry = false;
+  // state of the last forward (for the VJP)
+  int last_B = 0; bool have_stash = false;
+  const void* final_h = nullptr; float *out_coef = nullptr, *out_mr = nullptr;
+  std::vector<const void*> hs_ptr; std::vector<int> hs_C;
+  std::vector<void*> cat_ptr;
+
+  ~UNet();
+  int build_plan();
+  int load(const char* name, const float* data, const long* shape, int ndim);
+  int finalize();
+  int ensure_workspace(int B);
+  int run(hipStream_t st, const float* x_nchw, const float* t, int B, float in_scale, float* out_nchw,
+          float* cov_nchw, float* feat_nchw, int save);
+  int vjp(hipStream_t st, const float* cot_nchw, float* gx_nchw);
+  int forward_impl(hipStream_t st, const float* x_nchw, const float* t, int B, float in_scale, float* out_nchw,
+                   float* cov_nchw, float* feat_nchw);
+  int vjp_impl(hipStream_t st, const float* cot_nchw, float* gx_nchw);
+  size_t esize() const { return dt == DT_BF16 ? 2 : 4; }
+};
+
+}  // namespace kdip

@@ -1,0 +1,157 @@
+"""UNet handle + DDPM tables (host side).
+
+Mirrors, for the hot path only:
+  * guided_diffusion.unet.UNetModel.forward(x, timesteps, y=None, return_feature=False)
+    (guided_diffusion/unet.py:636-668) -- backed by kdip_unet_forward / kdip_unet_vjp;
+  * script_util.create_model_and_diffusion (guided_diffusion/script_util.py:74-184) with the
+    defaults of condition/diffpir_utils/utils_model.py:353-387;
+  * the float64 tables of GaussianDiffusion / SpacedDiffusion
+    (guided_diffusion/gaussian_diffusion.py:118-169, respace.py:63-91).
+"""
+import ctypes as C
+import math
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+class GaussianDiffusionTables:
+    """float64 numpy tables; attribute names match GaussianDiffusion."""
+
+    def __init__(self, steps=1000):
+        scale = 1000 / steps
+        base = np.linspace(scale * 0.0001, scale * 0.02, steps, dtype=np.float64)   # gaussian_diffusion.py:27-35
+        base_ac = np.cumprod(1.0 - base, axis=0)
+        last, nb = 1.0, []
+        for ac in base_ac:                                # respace.py:71-80 (identity respacing still re-derives betas)
+            nb.append(1 - ac / last)
+            last = ac
+        betas = np.array(nb, dtype=np.float64)
+        self.num_timesteps = steps
+        self.betas = betas
+        alphas = 1.0 - betas
+        self.alphas_cumprod = np.cumprod(alphas, axis=0)
+        self.alphas_cumprod_prev = np.append(1.0, self.alphas_cumprod[:-1])
+        self.sqrt_recip_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod)
+        self.sqrt_recipm1_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod - 1)
+        self.posterior_variance = betas * (1.0 - self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_log_variance_clipped = np.log(np.append(self.posterior_variance[1], self.posterior_variance[1:]))
+        self.posterior_mean_coef1 = betas * np.sqrt(self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.log_betas = np.log(betas)
+
+    def f32(self, name, t):
+        """_extract_into_tensor semantics: float64 table entry cast to fp32 (gaussian_diffusion.py:904)."""
+        return float(np.float32(getattr(self, name)[int(t)]))
+
+
+def _channel_mult_default(image_size):
+    # guided_diffusion/script_util.py:148-160
+    return {512: (0.5, 1, 1, 2, 2, 4, 4), 256: (1, 1, 2, 2, 4, 4), 128: (1, 1, 2, 3, 4), 64: (1, 2, 3, 4)}[image_size]
+
+
+class UNetModel:
+    """Device-resident ADM UNet.  Not an nn.Module: weights live in MFMA fragment order
+    inside libkdip_hip; `load_state_dict` takes the reference checkpoint layout."""
+
+    def __init__(self, image_size=256, model_channels=128, num_res_blocks=1, attention_resolutions="16",
+                 channel_mult="", num_head_channels=64, in_channels=3, out_channels=6, dtype="bf16", device=None):
+        L.require_gpu()
+        self.lib = L.load()
+        if channel_mult in ("", None, ()):
+            cm = _channel_mult_default(image_size)
+        elif isinstance(channel_mult, str):
+            cm = tuple(int(c) for c in channel_mult.split(","))
+        else:
+            cm = tuple(channel_mult)
+        if any(int(c) != c for c in cm):
+            raise ValueError("fractional channel_mult is not supported")
+        self.image_size, self.model_channels, self.out_channels, self.in_channels = image_size, model_channels, out_channels, in_channels
+        self.channel_mult = tuple(int(c) for c in cm)
+        self.attention_ds = tuple(image_size // int(r) for r in str(attention_resolutions).split(","))
+        self.dtype = dtype
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.device = dev
+        h = C.c_void_p()
+        ads = (C.c_int * len(self.attention_ds))(*self.attention_ds)
+        cms = (C.c_int * len(self.channel_mult))(*self.channel_mult)
+        L.check(self.lib.kdip_unet_create(dev.index or 0, L.BF16 if dtype == "bf16" else L.F32, image_size, in_channels,
+                                          model_channels, out_channels, num_res_blocks, ads, len(self.attention_ds),
+                                          cms, len(self.channel_mult), num_head_channels, C.byref(h)))
+        self._h = h
+        self._finalized = False
+        self.has_out_cov = False
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self.lib.kdip_unet_destroy(h)
+            self._h = None
+
+    def load_state_dict(self, state_dict, strict=True):
+        """Accepts the reference key layout (input_blocks.N.M..., middle_block..., output_blocks...,
+        out..., time_embed...) plus optional out_cov.* (OpenAIDenoiserV2)."""
+        for k, v in state_dict.items():
+            a = v.detach().to("cpu", torch.float32).contiguous()
+            shape = (C.c_long * a.ndim)(*a.shape)
+            L.check(self.lib.kdip_unet_load(self._h, k.encode(), C.c_void_p(a.data_ptr()), shape, a.ndim))
+            if k.startswith("out_cov."):
+                self.has_out_cov = True
+        L.check(self.lib.kdip_unet_finalize(self._h))     # raises on missing / mis-shaped parameters
+        self._finalized = True
+        return self
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def forward_raw(self, x, t, in_scale=1.0, want_cov=False, want_feature=False):
+        """x [B,3,S,S] fp32 cuda, t [B] float.  Returns (out[B,6,S,S], cov|None, feature|None)."""
+        assert x.is_cuda and x.dtype == torch.float32
+        B = x.shape[0]
+        x = x.contiguous()
+        t = t.to(device=x.device, dtype=torch.float32).contiguous()
+        out = torch.empty(B, self.out_channels, self.image_size, self.image_size, device=x.device, dtype=torch.float32)
+        cov = torch.empty(B, 6, self.image_size, self.image_size, device=x.device) if want_cov else None
+        feat = torch.empty(B, self.channel_mult[0] * self.model_channels, self.image_size, self.image_size,
+                           device=x.device) if want_feature else None
+        L.check(self.lib.kdip_unet_forward(self._h, L.stream(), L.ptr(x), L.ptr(t), B, float(in_scale), L.ptr(out),
+                                           L.ptr(cov), L.ptr(feat)))
+        return out, cov, feat
+
+    def vjp(self, cot):
+        """(d out / d x_in)^T cot for the last forward; cot [B,6,S,S] -> [B,3,S,S]."""
+        cot = cot.contiguous()
+        gx = torch.empty(cot.shape[0], self.in_channels, self.image_size, self.image_size, device=cot.device)
+        L.check(self.lib.kdip_unet_vjp(self._h, L.stream(), L.ptr(cot), L.ptr(gx)))
+        return gx
+
+    def forward(self, x, timesteps, y=None, return_feature=False):
+        assert y is None, "class conditioning is not on the sampler path"
+        out, _, feat = self.forward_raw(x, timesteps, want_feature=return_feature)
+        return (out, feat) if return_feature else out
+
+    __call__ = forward
+
+    def workspace_bytes(self, B):
+        return int(self.lib.kdip_unet_workspace_bytes(self._h, B))
+
+
+FFHQ_CONFIG = dict(image_size=256, model_channels=128, num_res_blocks=1, attention_resolutions="16")
+IMAGENET_CONFIG = dict(image_size=256, model_channels=256, num_res_blocks=2, attention_resolutions="8,16,32")
+
+
+def create_model_and_diffusion(image_size=256, num_channels=128, num_res_blocks=1, attention_resolutions="16",
+                               channel_mult="", num_head_channels=64, learn_sigma=True, dtype="bf16", device=None,
+                               diffusion_steps=1000, **unused):
+    """script_util.create_model_and_diffusion for the sampler's configuration
+    (resblock_updown, use_scale_shift_norm, learn_sigma, linear schedule, no respacing)."""
+    for k, want in (("resblock_updown", True), ("use_scale_shift_norm", True), ("class_cond", False)):
+        if k in unused and unused[k] != want:
+            raise ValueError(f"{k}={unused[k]} is not supported on the MI355X path")
+    model = UNetModel(image_size=image_size, model_channels=num_channels, num_res_blocks=num_res_blocks,
+                      attention_resolutions=attention_resolutions, channel_mult=channel_mult,
+                      num_head_channels=num_head_channels, out_channels=6 if learn_sigma else 3, dtype=dtype, device=device)
+    return model, GaussianDiffusionTables(diffusion_steps)
