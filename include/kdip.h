@@ -130,8 +130,9 @@ int kdip_guidance_combine(void* stream, const float* x0_mean_dev, const float* g
 int kdip_axpby(void* stream, const float* x_dev, float a, const float* y_dev, float b, long n, float* out_dev);
 int kdip_mul(void* stream, const float* x_dev, const float* y_dev, long n, float* out_dev);
 int kdip_clamp(void* stream, const float* x_dev, long n, float* out_dev);
-/* DPS: out[b] = zeta * x[b] / ||r[b]||_2 (per-sample norm; condition/condition.py:140-148). */
-int kdip_dps_normalize(void* stream, const float* x_dev, const float* r_dev, float zeta, int B, long per_sample,
+/* DPS: out[b] = zeta * x[b] / ||r[b]||_2 (per-sample norm; condition/condition.py:140-148).
+ * x [B, per_x], r [B, per_r]; norm_out_dev [B] fp32, tmp_dev [B] fp64 scratch. */
+int kdip_dps_normalize(void* stream, const float* x_dev, long per_x, const float* r_dev, long per_r, float zeta, int B,
                        float* out_dev, float* norm_out_dev, double* tmp_dev);
 
 /* ------------------------------------------------------------- sampler updates (row A2)

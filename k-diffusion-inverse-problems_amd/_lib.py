@@ -46,7 +46,7 @@ SIGNATURES = {
     "kdip_axpby": (C.c_int, [VP, VP, C.c_float, VP, C.c_float, C.c_long, VP]),
     "kdip_mul": (C.c_int, [VP, VP, VP, C.c_long, VP]),
     "kdip_clamp": (C.c_int, [VP, VP, C.c_long, VP]),
-    "kdip_dps_normalize": (C.c_int, [VP, VP, VP, C.c_float, C.c_int, C.c_long, VP, VP, VP]),
+    "kdip_dps_normalize": (C.c_int, [VP, VP, C.c_long, VP, C.c_long, C.c_float, C.c_int, VP, VP, VP]),
     "kdip_sampler_add_noise": (C.c_int, [VP, VP, VP, C.c_float, C.c_long, VP]),
     "kdip_sampler_euler": (C.c_int, [VP, VP, VP, C.c_float, C.c_float, C.c_long, VP]),
     "kdip_sampler_heun": (C.c_int, [VP, VP, VP, VP, VP, C.c_float, C.c_float, C.c_float, C.c_long, VP]),

@@ -165,9 +165,10 @@ int kdip_guidance_combine(void* stream, const float* x0, const float* gd, float 
 int kdip_axpby(void* stream, const float* x, float a, const float* y, float b, long n, float* out) { return axpby(ST(stream), x, a, y, b, n, out); }
 int kdip_mul(void* stream, const float* x, const float* y, long n, float* out) { return mul_elem(ST(stream), x, y, n, out); }
 int kdip_clamp(void* stream, const float* x, long n, float* out) { return clamp_pm1(ST(stream), x, n, out); }
-int kdip_dps_normalize(void* stream, const float* x, const float* r, float zeta, int B, long per, float* out, float* nrm, double* tmp) {
-  API_CK(norm_per_sample(ST(stream), r, B, per, nrm, tmp));
-  return scale_per_sample_inv(ST(stream), x, nrm, zeta, B, per, out);
+int kdip_dps_normalize(void* stream, const float* x, long per_x, const float* r, long per_r, float zeta, int B, float* out,
+                       float* nrm, double* tmp) {
+  API_CK(norm_per_sample(ST(stream), r, B, per_r, nrm, tmp));
+  return scale_per_sample_inv(ST(stream), x, nrm, zeta, B, per_x, out);
 }
 
 int kdip_sampler_add_noise(void* stream, const float* x, const float* eps, float s, long n, float* out) { return sampler_add_noise(ST(stream), x, eps, s, n, out); }

@@ -18,7 +18,7 @@ namespace kdip {
 
 template <int N>
 __device__ inline int bitrev(int i) {
-  constexpr int LG = (N == 256) ? 8 : (N == 64 ? 6 : 0);
+  constexpr int LG = (N == 256) ? 8 : (N == 64 ? 6 : (N == 16 ? 4 : 0));
   return (int)(__brev((unsigned)i) >> (32 - LG));
 }
 
@@ -102,7 +102,8 @@ int fft2(hipStream_t st, const float2* tw256, int N, const void* in, int real_in
          long planes, int inverse) {
   if (N == 256) return fft2_N<256>(st, tw256, in, real_in, tmp, out, real_out, planes, inverse);
   if (N == 64) return fft2_N<64>(st, tw256, in, real_in, tmp, out, real_out, planes, inverse);
-  return set_error(KDIP_ERR_UNSUPPORTED, "fft2: N=%d (supported: 64, 256)", N);
+  if (N == 16) return fft2_N<16>(st, tw256, in, real_in, tmp, out, real_out, planes, inverse);
+  return set_error(KDIP_ERR_UNSUPPORTED, "fft2: N=%d (supported: 16, 64, 256)", N);
 }
 
 void make_twiddles256(float2* host) {

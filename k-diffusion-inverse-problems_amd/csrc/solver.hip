@@ -271,7 +271,7 @@ int OpCtx::solve(hipStream_t st, const float* y, const float* x0, float v, const
   CK(strided_down(st, ax, N, sf, P, d));
   CK(axpby(st, y, 1.f, d, -1.f, nsm, b));                 // y - down(A x0)
   if (!vt) {
-    KDIP_REQUIRE(ns == 64 || ns == 256, "SR: low-res size %d unsupported", ns);
+    KDIP_REQUIRE(ns == 16 || ns == 64 || ns == 256, "SR: low-res size %d unsupported", ns);
     CK(fft2(st, tw, ns, b, 1, ctmp, c0, 0, P, 0));
     CK(sr_solve_tile(st, c0, invW, FB, N, sf, P, s2, v, c1));      // condition.py:409-410
     return fft2(st, tw, N, c1, 0, ctmp, mat, 1, P, 1);

@@ -1,0 +1,92 @@
+"""Multi-process evaluation helper -- k_diffusion/evaluation.py:53-63 (`compute_features`).
+
+One process per GPU; the n samples are split over the processes, sampled independently
+(no communication inside the sampler loop) and gathered once at the end with a
+torch.distributed all_gather (backend "nccl" = RCCL over xGMI on MI355X, "gloo" on CPU).
+`DistEnv` is the minimal stand-in for the `accelerate.Accelerator` attributes the
+reference uses (num_processes, is_main_process, gather, device).
+"""
+import math
+import os
+
+import torch
+import torch.distributed as dist
+
+
+class DistEnv:
+    def __init__(self, backend=None, init=True):
+        self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        use_cuda = torch.cuda.is_available()
+        if use_cuda:
+            torch.cuda.set_device(self.local_rank)
+        self.device = torch.device("cuda", self.local_rank) if use_cuda else torch.device("cpu")
+        if init and self.world_size > 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            backend = backend or ("nccl" if use_cuda else "gloo")
+            kw = {}
+            if backend == "nccl":
+                kw["device_id"] = self.device
+            dist.init_process_group(backend, rank=self.rank, world_size=self.world_size, **kw)
+
+    @property
+    def num_processes(self):
+        return self.world_size
+
+    @property
+    def is_main_process(self):
+        return self.rank == 0
+
+    is_local_main_process = is_main_process
+
+    def gather(self, t):
+        """all_gather along dim 0 (accelerator.gather)."""
+        if self.world_size == 1:
+            return t
+        t = t.contiguous()
+        out = [torch.empty_like(t) for _ in range(self.world_size)]
+        dist.all_gather(out, t)
+        return torch.cat(out)
+
+    def barrier(self):
+        if self.world_size > 1:
+            dist.barrier()
+
+    def max_over_ranks(self, value):
+        if self.world_size == 1:
+            return value
+        t = torch.tensor([value], dtype=torch.float64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0])
+
+
+def shard_range(n, rank, world):
+    """Contiguous split of n items: rank r gets [lo, hi)."""
+    per = math.ceil(n / world)
+    lo = min(rank * per, n)
+    return lo, min(lo + per, n)
+
+
+def compute_features(accelerator, sample_fn, extractor_fn, n, batch_size):
+    """Each process draws ceil(n / P) samples in chunks of `batch_size`; chunks are
+    all-gathered and the concatenation truncated to n (evaluation.py:53-63)."""
+    n_per_proc = math.ceil(n / accelerator.num_processes)
+    feats_all = []
+    try:
+        for i in range(0, n_per_proc, batch_size):
+            cur_batch_size = min(n - i, batch_size)
+            samples = sample_fn(cur_batch_size)[:cur_batch_size]
+            feats_all.append(accelerator.gather(extractor_fn(samples)))
+    except StopIteration:
+        pass
+    return torch.cat(feats_all)[:n]
+
+
+def psnr(hat_x0, x0):
+    """PSNR of compute_metrics (sample_condition_openai.py:41-44): images mapped to [0,1]."""
+    a = (hat_x0 / 2 + 0.5).clip(0, 1)
+    b = (x0 / 2 + 0.5).clip(0, 1)
+    mse = ((a - b) ** 2).flatten(1).mean(dim=1)
+    return 10 * torch.log10(1.0 / mse)
