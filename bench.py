@@ -1,0 +1,226 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: BASELINE.json configs[1] -- FFHQ 256x256 Gaussian deblur, Type-I
+guidance with Convert posterior covariance, 100 Heun steps, batch 16 per MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one Heun sampler step of the 100-step Karras schedule over one batch of 16 synthetic
+images (2 guided-denoiser calls = 2 UNet forwards + 2 hand-written UNet VJPs + 2 mat-solves, CG
+on the sigma < 0.2 steps).  With K = 100 (default) the timed region is the whole sampler run; with
+K < 100 the K timed steps are spread evenly over the schedule (so the closed-form / CG mix is
+preserved) and each starts from x0 + sigma_i * noise.  Inputs are resident in HBM before the
+timed region.  value = images/s of the whole job = N * 16 / (100 * seconds_per_step).
+
+Extra objects on the JSON line:
+  roofline     dominant kernel (bf16 3x3 implicit-GEMM conv): algorithmic FLOPs / HIP-event time,
+               measured live in an extra profiled pass after the timed region
+  cpu_baseline the CPU oracle (torch-CPU fp32 restatement of the reference, oracle/) timed on the
+               host cores on a bounded sample (rank 0, N = 1 only)
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BF16_MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+CALLS_PER_IMAGE = 199               # 100 Heun steps, last one Euler
+FWD_VJP_GFLOP_PER_IMAGE_CALL = 776.26   # FFHQ UNet forward + input-VJP, 2*MAC
+
+
+def smooth_image(B, size, seed):
+    g = torch.Generator().manual_seed(seed)
+    r = torch.rand(B, 3, size, size, generator=g) * 2 - 1
+    rp = torch.nn.functional.pad(r, (4, 4, 4, 4), mode="circular")
+    return (3 * torch.nn.functional.avg_pool2d(rp, 9, 1)).clamp(-1, 1)
+
+
+def step_indices(K, n=100):
+    if K >= n:
+        return list(range(n)) * (K // n) + list(range(K % n))
+    if K == 1:
+        return [n // 2]
+    return [int(round(j * (n - 1) / (K - 1))) for j in range(K)]
+
+
+def available_cores():
+    """Host cores this process may actually use: min(affinity mask, cgroup v2/v1 CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return n
+
+
+def cpu_baseline(sig):
+    """Oracle (kind 'port') timed on the host: 2 high-sigma + 2 low-sigma Type-I/Convert calls at
+    batch 1, extrapolated with the schedule's 157 closed-form + 42 CG calls per image."""
+    from oracle import unet as ounet, operators as oops, condition as ocond
+    ncores = available_cores()
+    torch.set_num_threads(ncores)
+    cfg = ounet.UNetConfig(**ounet.FFHQ)
+    sd = ounet.init_state_dict(cfg, seed=0)
+    x0 = smooth_image(1, 256, 1)
+    op = oops.get_operator("gaussian_blur", in_shape=(1, 3, 256, 256), kernel_size=61, intensity=3.0, sigma_s=0.05)
+    torch.manual_seed(2)
+    meas = op.forward(x0.clone(), flatten=True)
+    model = ocond.GuidedDenoiser(sd, cfg, op, meas, "I", x0_cov_type="convert")
+    times = {}
+    for tag, i in (("hi", 10), ("lo", 95)):
+        s = float(sig[i])
+        x = x0 + s * torch.randn(1, 3, 256, 256, generator=torch.Generator().manual_seed(3))
+        model(x, torch.tensor([s]))                       # warm-up (thread pool, allocator)
+        t0 = time.perf_counter()
+        for _ in range(2):
+            model(x, torch.tensor([s]))
+        times[tag] = (time.perf_counter() - t0) / 2
+    n_lo = 42
+    sec_per_image = (CALLS_PER_IMAGE - n_lo) * times["hi"] + n_lo * times["lo"]
+    return {"value": 1.0 / sec_per_image, "unit": "images/s", "cores": ncores, "kind": "port",
+            "s_per_call_closed_form": round(times["hi"], 4), "s_per_call_cg": round(times["lo"], 4),
+            "sample": "oracle (torch-CPU fp32 restatement, validated against the reference) at batch 1: 2 timed "
+                      "Type-I/Convert guided calls at sigma=%.3g (closed form) + 2 at sigma=%.3g (CG branch), "
+                      "extrapolated to 157 + 42 calls = 100 Heun steps" % (float(sig[10]), float(sig[95]))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import kdip_amd._lib as L
+    import kdip_amd.unet as ku
+    import kdip_amd.condition as kc
+    import kdip_amd.measurements as km
+    import kdip_amd.sampling as ks
+    from kdip_amd.evaluation import DistEnv
+
+    env = DistEnv()
+    assert env.world_size == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={env.world_size}"
+    L.require_gpu()
+    dev = env.device
+    B, S, rank = args.batch, 256, env.rank
+    lib = L.load()
+
+    # ---- model (random-init weights of the named architecture; no checkpoint is obtainable offline)
+    model = ku.UNetModel(dtype="bf16", device=dev, **ku.FFHQ_CONFIG)
+    model.load_state_dict(ku.synthetic_state_dict(seed=0, **ku.FFHQ_CONFIG))
+    D = ku.GaussianDiffusionTables()
+    # ---- operator + synthetic measurement (sigma_s = 0.05), rank-offset seeds: every image is its own problem
+    op = km.get_operator("gaussian_blur", device=dev, in_shape=(1, 3, S, S), kernel_size=61, intensity=3.0, sigma_s=0.05)
+    x0 = smooth_image(B, S, seed=1 + 1000 * rank).to(dev)
+    torch.manual_seed(2 + 1000 * rank)
+    meas = op.forward(x0.clone(), flatten=True)
+    den = kc.ConditionOpenAIDenoiser(inner_model=model, diffusion=D, x0_cov_type="convert", recon_mse=None, operator=op,
+                                     measurement=meas, guidance="I", mle_sigma_thres=0.2, device=dev).eval()
+    sigmas = ks.get_sigmas_karras(100, 0.01, 80, rho=7.0, device=dev)
+    sig = sigmas.detach().cpu()
+    noise = torch.randn(B, 3, S, S, device=dev, generator=torch.Generator(device=dev).manual_seed(3 + 1000 * rank))
+
+    def start_state(i):
+        return (x0 + float(sig[i]) * noise).contiguous() if i > 0 else (noise * float(sig[0])).contiguous()
+
+    full_run = args.steps % 100 == 0 and args.steps > 0
+    idx = step_indices(args.steps)
+
+    # ---- warm-up: one closed-form step and one CG step (allocates the workspaces)
+    for w in range(max(args.warmup, 0)):
+        i = 10 if w % 2 == 0 else 95
+        ks.heun_step(den, start_state(i), sig, i)
+    torch.cuda.synchronize()
+
+    # ---- timed region
+    env.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    x = start_state(0)
+    for n, i in enumerate(idx):
+        if not full_run or i == 0:
+            x = start_state(i)
+        x = ks.heun_step(den, x, sig, i)
+    hat = env.gather(x)                                   # the one collective of the path (RCCL all_gather)
+    torch.cuda.synchronize()
+    env.barrier()
+    elapsed = env.max_over_ranks(time.perf_counter() - t0)
+    assert torch.isfinite(hat).all()
+
+    ms_per_step = elapsed / args.steps * 1e3
+    images_per_s = env.world_size * B / (ms_per_step * 100 / 1e3)
+    out = {
+        "metric": "images/sec (256x256 FFHQ Gaussian deblur, Type-I + Convert, 100 Heun steps)",
+        "value": round(images_per_s, 5), "unit": "images/s", "n_gpus": env.world_size, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic (seeded smooth images, random-init FFHQ-architecture weights)",
+        "config": {"workload": "BASELINE configs[1]: FFHQ 256x256 Gaussian deblur (61x61 PSF, sigma_s=0.05), Type-I guidance, "
+                               "Convert covariance (CG below sigma 0.2), 100 Heun steps (--ode), batch 16 per GPU",
+                   "global_batch": env.world_size * B, "per_gpu_batch": B, "calls_per_image": CALLS_PER_IMAGE,
+                   "timed_steps": "full 100-step sampler run" if full_run else "evenly spaced subset of the 100-step schedule",
+                   "parallelism": f"dp{env.world_size} (independent images, one all_gather at the end)"},
+        "achieved_tflops_whole_step": round(2 * B * FWD_VJP_GFLOP_PER_IMAGE_CALL / ms_per_step, 2),
+    }
+
+    # ---- roofline leg: per-launch HIP-event timing of the conv kernels on two representative steps
+    if not args.no_roofline and env.is_main_process:
+        L.check(lib.kdip_profile_enable(1))
+        for i in (10, 95):
+            ks.heun_step(den, start_state(i), sig, i)
+        torch.cuda.synchronize()
+        n = lib.kdip_profile_num_classes()
+        ms = (C.c_double * n)(); fl = (C.c_double * n)(); by = (C.c_double * n)(); la = (C.c_long * n)()
+        L.check(lib.kdip_profile_report(ms, fl, by, la))
+        L.check(lib.kdip_profile_enable(0))
+        k = max(range(n), key=lambda j: ms[j])
+        tflops = fl[k] / (ms[k] * 1e-3) / 1e12 if ms[k] > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_conv3x3_latest.json")   # filled from rocprofv3 --pmc passes, if committed
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out["roofline"] = {
+            "kernel": lib.kdip_profile_class_name(k).decode() + " (bf16, v_mfma_f32_32x32x16_bf16)",
+            "bound": "mfma", "achieved": round(tflops, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tflops / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+            "launches": int(la[k]), "avg_launch_us": round(ms[k] * 1e3 / max(la[k], 1), 2),
+            "algorithmic_gflop_per_launch": round(fl[k] / max(la[k], 1) / 1e9, 3),
+            "share_of_profiled_conv_time": round(ms[k] / max(sum(ms), 1e-9), 3),
+            "all_conv_classes": {lib.kdip_profile_class_name(j).decode(): {"ms": round(ms[j], 3), "tflops": round(fl[j] / max(ms[j], 1e-9) / 1e9, 2), "launches": int(la[j])}
+                                 for j in range(n) if la[j] > 0},
+        }
+
+    # ---- CPU baseline (rank 0, single-GPU runs only; bounded sample)
+    if not args.no_cpu_baseline and env.is_main_process and env.world_size == 1:
+        cb = cpu_baseline(sig)
+        out["cpu_baseline"] = cb
+        out["speedup_vs_cpu_baseline"] = round(images_per_s / cb["value"], 1)
+
+    if env.is_main_process:
+        print(json.dumps(out))
+    env.barrier()
+
+
+if __name__ == "__main__":
+    main()

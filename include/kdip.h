@@ -143,6 +143,16 @@ int kdip_sampler_euler(void* stream, const float* x_dev, const float* denoised_d
 int kdip_sampler_heun(void* stream, const float* x_dev, const float* denoised_dev, const float* x2_dev,
                       const float* denoised2_dev, float sigma_hat, float sigma_next, float dt, long n, float* out_dev);
 
+/* --------------------------------------------------------------------------- profiling
+ * Opt-in per-launch timing of the implicit-GEMM conv kernels with HIP events recorded on the
+ * launch stream (bench.py's roofline leg).  enable(1) clears and starts recording, enable(0)
+ * stops; report() synchronises the recorded events and fills per-class totals: milliseconds,
+ * algorithmic FLOPs (2*B*H*W*Cin*Cout*taps, un-padded), minimal HBM bytes, launch count. */
+int kdip_profile_enable(int on);
+int kdip_profile_num_classes(void);
+const char* kdip_profile_class_name(int cls);
+int kdip_profile_report(double* ms, double* flops, double* bytes, long* launches);
+
 /* ------------------------------------------------------------------ low-level test hooks
  * (exercised by tests/ to localise kernel bugs; NHWC tensors of the UNet storage dtype) */
 int kdip_test_conv(void* stream, int dtype, int ntaps, const float* x_nchw_dev, int B, int Cin, int H, int W,

@@ -50,6 +50,10 @@ SIGNATURES = {
     "kdip_sampler_add_noise": (C.c_int, [VP, VP, VP, C.c_float, C.c_long, VP]),
     "kdip_sampler_euler": (C.c_int, [VP, VP, VP, C.c_float, C.c_float, C.c_long, VP]),
     "kdip_sampler_heun": (C.c_int, [VP, VP, VP, VP, VP, C.c_float, C.c_float, C.c_float, C.c_long, VP]),
+    "kdip_profile_enable": (C.c_int, [C.c_int]),
+    "kdip_profile_num_classes": (C.c_int, []),
+    "kdip_profile_class_name": (C.c_char_p, [C.c_int]),
+    "kdip_profile_report": (C.c_int, [VP, VP, VP, VP]),
     "kdip_test_conv": (C.c_int, [VP, C.c_int, C.c_int, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, C.c_int, C.c_int, VP]),
     "kdip_test_groupnorm": (C.c_int, [VP, C.c_int, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, VP, C.c_int, VP, VP, VP]),
 }

@@ -1,5 +1,6 @@
 #include "common.h"
 #include <stdarg.h>
+#include <vector>
 namespace kdip {
 thread_local std::string g_last_error;
 int set_error(int code, const char* fmt, ...) {
@@ -11,4 +12,45 @@ int set_error(int code, const char* fmt, ...) {
   g_last_error = buf;
   return code;
 }
+
+bool g_prof_on = false;
+struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; };
+static std::vector<ProfRec> g_recs;
+static ProfRec g_cur;
+void prof_begin(hipStream_t st, int cls, double flops, double bytes) {
+  if (!g_prof_on) return;
+  g_cur.cls = cls; g_cur.flops = flops; g_cur.bytes = bytes;
+  (void)hipEventCreate(&g_cur.a); (void)hipEventCreate(&g_cur.b);
+  (void)hipEventRecord(g_cur.a, st);
+}
+void prof_end(hipStream_t st) {
+  if (!g_prof_on) return;
+  (void)hipEventRecord(g_cur.b, st);
+  g_recs.push_back(g_cur);
+}
+static const char* kClassNames[PC_COUNT] = {"conv3x3_igemm_128x128", "conv3x3_igemm_128x64", "conv3x3_igemm_128x32",
+                                            "conv1x1_igemm_128x128", "conv1x1_igemm_128x64", "conv1x1_igemm_128x32"};
 }  // namespace kdip
+
+extern "C" {
+int kdip_profile_enable(int on) {
+  using namespace kdip;
+  for (auto& r : g_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  g_recs.clear();
+  g_prof_on = on != 0;
+  return 0;
+}
+int kdip_profile_num_classes(void) { return kdip::PC_COUNT; }
+const char* kdip_profile_class_name(int cls) { return (cls >= 0 && cls < kdip::PC_COUNT) ? kdip::kClassNames[cls] : "?"; }
+int kdip_profile_report(double* ms, double* flops, double* bytes, long* launches) {
+  using namespace kdip;
+  for (int i = 0; i < PC_COUNT; ++i) { ms[i] = 0; flops[i] = 0; bytes[i] = 0; launches[i] = 0; }
+  for (auto& r : g_recs) {
+    if (hipEventSynchronize(r.b) != hipSuccess) return set_error(KDIP_ERR_HIP, "profile: event sync failed");
+    float t = 0;
+    if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return set_error(KDIP_ERR_HIP, "profile: elapsed failed");
+    ms[r.cls] += t; flops[r.cls] += r.flops; bytes[r.cls] += r.bytes; launches[r.cls] += 1;
+  }
+  return 0;
+}
+}

@@ -115,4 +115,11 @@ __device__ inline float wave_max(float v) {
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// ---- opt-in per-launch profiler (HIP events on the launch stream; used by bench.py's roofline leg) ----
+enum ProfClass { PC_CONV3_128x128 = 0, PC_CONV3_128x64, PC_CONV3_128x32, PC_CONV1_128x128, PC_CONV1_128x64,
+                 PC_CONV1_128x32, PC_COUNT };
+extern bool g_prof_on;
+void prof_begin(hipStream_t st, int cls, double flops, double bytes);
+void prof_end(hipStream_t st);
+
 }  // namespace kdip

@@ -52,6 +52,7 @@ struct ConvParams {
   int tilesX, tilesY, mtiles;     // per-image tiles, total M tiles
   int out_f32;                    // store fp32 regardless of T
   float alpha;                    // output scale (applied before bias)
+  int cin_real;                   // un-padded input channels (profiling / algorithmic FLOPs only)
 };
 
 constexpr int KC = 32;            // input channels per LDS chunk
@@ -66,7 +67,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(ConvP
   constexpr int PIXB = KC * (int)sizeof(T) + 16;       // padded LDS pixel stride (bytes)
   constexpr int VPP = KC * (int)sizeof(T) / 16;        // 16-byte vectors per pixel-chunk
   constexpr int HALO = (NTAPS == 9) ? 1 : 0;
-  constexpr int MAXV = (sizeof(T) == 2) ? 4 : 8;       // staged vectors per thread (<=256 halo pixels)
+  constexpr int MAXPIX = (BM == 256) ? 400 : 256;      // halo pixels: 18x18 (one 16x16 patch) or 4 x 10x10
+  constexpr int MAXV = (MAXPIX * VPP + NTHREADS - 1) / NTHREADS;   // staged 16-byte vectors per thread
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -155,11 +157,20 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(ConvP
   stage_write(0);
   __syncthreads();
 
-  uint4 bcur[KS][NT], bnxt[KS][NT];
+  // B fragments are software-pipelined two stages (= taps) ahead in registers; a stage index past
+  // the end is clamped to the last stage (one redundant L2 hit) so the loop body has no branches.
+  const int nstages = nchunks * NTAPS;
+  auto load_b = [&](uint4 (&dst)[KS][NT], int stage) {
+    stage = stage < nstages ? stage : nstages - 1;
+    const int cc = stage / NTAPS, tp = stage - cc * NTAPS;
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks)
+    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bcur[ks][nt] = *bptr(0, ks, nt);
+      for (int nt = 0; nt < NT; ++nt) dst[ks][nt] = *bptr(tp, (long)cc * KS + ks, nt);
+  };
+  uint4 bq0[KS][NT], bq1[KS][NT], bq2[KS][NT];
+  load_b(bq0, 0);
+  load_b(bq1, 1);
 
   for (int c = 0; c < nchunks; ++c) {
     const int buf = c & 1;
@@ -167,18 +178,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(ConvP
     const unsigned char* abuf = smem + buf * abuf_bytes;
 #pragma unroll
     for (int tap = 0; tap < NTAPS; ++tap) {
-      // prefetch next tap's (or next chunk's first) B fragments
-      {
-        int ntap = tap + 1;
-        long kbase = (long)c * KS;
-        if (ntap == NTAPS) { ntap = 0; kbase += KS; }
-        if (kbase < kstepsTotal) {
-#pragma unroll
-          for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bnxt[ks][nt] = *bptr(ntap, kbase + ks, nt);
-        }
-      }
+      load_b(bq2, c * NTAPS + tap + 2);
       const int toff = (NTAPS == 9) ? ((tap / 3) * HW_ + (tap % 3)) * PIXB : 0;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
@@ -188,12 +188,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(ConvP
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) Mma<T>::run(a[mt], bcur[ks][nt], acc[mt][nt]);
+          for (int nt = 0; nt < NT; ++nt) Mma<T>::run(a[mt], bq0[ks][nt], acc[mt][nt]);
       }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bcur[ks][nt] = bnxt[ks][nt];
+        for (int nt = 0; nt < NT; ++nt) { bq0[ks][nt] = bq1[ks][nt]; bq1[ks][nt] = bq2[ks][nt]; }
     }
     if (c + 1 < nchunks) stage_write(buf ^ 1);
     __syncthreads();
@@ -243,34 +243,49 @@ static int launch_cfg(ConvParams& p, hipStream_t st) {
   p.tilesX = p.W / TW; p.tilesY = p.H / TH;
   p.mtiles = cdiv(p.B, TB) * p.tilesX * p.tilesY;
   int npix = TB * (TH + 2 * HALO) * (TW + 2 * HALO);
-  if (npix > 256) return set_error(KDIP_ERR_UNSUPPORTED, "conv: halo patch too large (%d px)", npix);
+  if (npix > (BM == 256 ? 400 : 256)) return set_error(KDIP_ERR_UNSUPPORTED, "conv: halo patch too large (%d px)", npix);
   size_t lds = (size_t)2 * npix * PIXB;
   int nblkN = cdiv(p.ntilesN * 32, BN);
   long grid = (long)p.mtiles * nblkN;
   auto kern = conv_igemm_kernel<T, NTAPS, WAVES_M, WAVES_N, MT, NT>;
+  if (g_prof_on) {
+    const int cls = (NTAPS == 9 ? 0 : 3) + (BN == 128 ? 0 : (BN == 64 ? 1 : 2));
+    const double px = (double)p.B * p.H * p.W;
+    prof_begin(st, cls, 2.0 * px * p.cin_real * p.Cout * NTAPS,
+               px * (p.cin_real + p.Cout) * sizeof(T) + (double)NTAPS * p.cin_real * p.Cout * sizeof(T));
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES_M * WAVES_N * 64), lds, st, p);
+  prof_end(st);
   KDIP_LAUNCH_CHECK();
   return KDIP_OK;
 }
 
 template <typename T, int NTAPS>
 static int launch_T(ConvParams& p, hipStream_t st) {
-  int npad = p.ntilesN * 32;
-  if (npad >= 128) return launch_cfg<T, NTAPS, 2, 2, 2, 2>(p, st);
+  const int npad = p.ntilesN * 32;
+  // All tiles are 128 pixels tall; pick the widest N tile that still gives >= 2 blocks per CU.
+  // Small-spatial layers (8x8 ... 32x32) are weight-streaming / latency bound: more, narrower
+  // blocks spread the weight reads over more CUs.
+  const long mt = cdiv((long)p.B * p.H * p.W, 128);
+  if (npad >= 128 && mt * cdiv(npad, 128) >= 512) return launch_cfg<T, NTAPS, 2, 2, 2, 2>(p, st);
+  if (npad >= 64 && mt * cdiv(npad, 64) >= 512) return launch_cfg<T, NTAPS, 2, 2, 2, 1>(p, st);
+  if (npad >= 128 && mt * cdiv(npad, 32) < 256) return launch_cfg<T, NTAPS, 4, 1, 1, 1>(p, st);
+  if (npad >= 64 && mt * cdiv(npad, 32) >= 512) return launch_cfg<T, NTAPS, 4, 1, 1, 1>(p, st);
+  if (npad >= 128) return launch_cfg<T, NTAPS, 2, 2, 2, 1>(p, st);
   if (npad >= 64) return launch_cfg<T, NTAPS, 2, 2, 2, 1>(p, st);
   return launch_cfg<T, NTAPS, 4, 1, 1, 1>(p, st);
 }
 
 int conv_forward(hipStream_t st, DType dt, int ntaps, const void* x, long ldx, int B, int H, int W, int Cin,
                  const void* wp, const float* bias, int Cout, void* y, long ldy, const void* res, long ldr,
-                 int out_f32, float alpha) {
+                 int out_f32, float alpha, int cin_real) {
   KDIP_REQUIRE(Cin % KC == 0, "conv: Cin=%d must be a multiple of %d (pad the input)", Cin, KC);
   KDIP_REQUIRE(ntaps == 9 || ntaps == 1, "conv: ntaps must be 9 or 1");
   KDIP_REQUIRE((ldx * (dt == DT_BF16 ? 2 : 4)) % 16 == 0, "conv: input channel stride must be 16-byte aligned");
   ConvParams p;
   p.x = x; p.ldx = ldx; p.wp = wp; p.bias = bias; p.res = res; p.ldr = ldr; p.y = y; p.ldy = ldy;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.ntilesN = cdiv(Cout, 32);
-  p.out_f32 = out_f32; p.alpha = alpha;
+  p.out_f32 = out_f32; p.alpha = alpha; p.cin_real = cin_real > 0 ? cin_real : Cin;
   if (dt == DT_BF16) return ntaps == 9 ? launch_T<bf16_t, 9>(p, st) : launch_T<bf16_t, 1>(p, st);
   return ntaps == 9 ? launch_T<float, 9>(p, st) : launch_T<float, 1>(p, st);
 }

@@ -7,7 +7,7 @@ namespace kdip {
 // ---- conv.hip ---------------------------------------------------------------------------
 int conv_forward(hipStream_t st, DType dt, int ntaps, const void* x, long ldx, int B, int H, int W, int Cin,
                  const void* wp, const float* bias, int Cout, void* y, long ldy, const void* res, long ldr,
-                 int out_f32, float alpha);
+                 int out_f32, float alpha, int cin_real = 0);
 size_t packed_weight_bytes(DType dt, int ntaps, int Cin_pad, int Cout);
 void pack_conv_weight(DType dt, const float* w, int Cout, int Cin, int ntaps, int transpose_flip, int Cin_pad_out,
                       void* out);

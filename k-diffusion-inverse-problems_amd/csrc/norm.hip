@@ -132,41 +132,56 @@ int gn_coef(hipStream_t st, const double* stats, const float* gamma, const float
 }
 
 // ------------------------------------------------------------------------------ apply ----
+// Thread = one fixed 16-byte channel vector (its 2*EPV coefficients stay in registers), walking
+// pixels of one image chunk: lanes sweep consecutive channel vectors of a pixel => coalesced.
 template <typename T>
 __global__ void gn_apply_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ coef, long HW, int C,
-                                int VP, long nvec, int silu, T* __restrict__ y, long ldy) {
+                                int VP, int lanes, long chunk, int silu, T* __restrict__ y, long ldy) {
   constexpr int EPV = TypeInfo<T>::EPV;
-  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (long)gridDim.x * blockDim.x) {
-    long pix = v / VP;
-    int vi = (int)(v % VP);
-    int b = (int)(pix / HW);
-    uint4 xv = *(const uint4*)(x + pix * ldx + (long)vi * EPV);
-    float f[EPV];
-    unpack16<T>(xv, f);
-    const float4* cp = (const float4*)(coef + ((long)b * C + (long)vi * EPV) * 2);
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const int vi = tid % VP, pl = tid / VP;
+  if (pl >= lanes) return;
+  float ca[EPV], cb[EPV];
 #pragma unroll
-    for (int e = 0; e < EPV; e += 2) {
-      float4 c4 = cp[e >> 1];
-      float z0 = c4.x * f[e] + c4.y, z1 = c4.z * f[e + 1] + c4.w;
-      f[e] = silu ? silu_f(z0) : z0;
-      f[e + 1] = silu ? silu_f(z1) : z1;
-    }
-    *(uint4*)(y + pix * ldy + (long)vi * EPV) = pack16<T>(f);
+  for (int e = 0; e < EPV; ++e) {
+    ca[e] = coef[((long)b * C + vi * EPV + e) * 2];
+    cb[e] = coef[((long)b * C + vi * EPV + e) * 2 + 1];
   }
+  long p0 = (long)blockIdx.x * chunk, p1 = p0 + chunk < HW ? p0 + chunk : HW;
+  const T* xb = x + ((long)b * HW) * ldx + (long)vi * EPV;
+  T* yb = y + ((long)b * HW) * ldy + (long)vi * EPV;
+  for (long p = p0 + pl; p < p1; p += lanes) {
+    float f[EPV];
+    unpack16<T>(*(const uint4*)(xb + p * ldx), f);
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+      float z = ca[e] * f[e] + cb[e];
+      f[e] = silu ? silu_f(z) : z;
+    }
+    *(uint4*)(yb + p * ldy) = pack16<T>(f);
+  }
+}
+
+static long pick_chunk_stream(long HW, int B) {
+  long want = (4096 + B - 1) / B;              // ~4096 blocks in flight
+  long chunk = (HW + want - 1) / want;
+  if (chunk < 64) chunk = 64;
+  return chunk;
 }
 
 int gn_apply(hipStream_t st, DType dt, const void* x, long ldx, const float* coef, int B, long HW, int C, int silu,
              void* y, long ldy) {
-  int EPV = dt == DT_BF16 ? 8 : 4;
-  int VP = C / EPV;
-  long nvec = (long)B * HW * VP;
-  int grid = (int)(nvec / 256 < 1 ? 1 : (nvec / 256 > 8192 ? 8192 : nvec / 256));
-  if (dt == DT_BF16)
-    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, ldx, coef, HW, C, VP,
-                       nvec, silu, (bf16_t*)y, ldy);
-  else
-    hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, ldx, coef, HW, C, VP,
-                       nvec, silu, (float*)y, ldy);
+  long chunk = pick_chunk_stream(HW, B);
+  dim3 grid(cdiv(HW, chunk), B);
+  if (dt == DT_BF16) {
+    GnGeom g = gn_geom<bf16_t>(C);
+    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(g.nthreads), 0, st, (const bf16_t*)x, ldx, coef, HW, C, g.VP,
+                       g.lanes, chunk, silu, (bf16_t*)y, ldy);
+  } else {
+    GnGeom g = gn_geom<float>(C);
+    hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(g.nthreads), 0, st, (const float*)x, ldx, coef, HW, C, g.VP,
+                       g.lanes, chunk, silu, (float*)y, ldy);
+  }
   KDIP_LAUNCH_CHECK();
   return KDIP_OK;
 }
@@ -243,49 +258,63 @@ int gn_bwd_stats(hipStream_t st, DType dt, const void* x, long ldx, const void* 
 template <typename T>
 __global__ void gn_bwd_apply_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy, long lddy,
                                     const float* __restrict__ coef, const float* __restrict__ mr,
-                                    const double* __restrict__ sums, long HW, int C, int VP, int cpg, long nvec,
-                                    int silu, const T* __restrict__ addend, long lda, T* __restrict__ dx, long lddx) {
+                                    const double* __restrict__ sums, long HW, int C, int VP, int lanes, int cpg,
+                                    long chunk, int silu, const T* __restrict__ addend, long lda, T* __restrict__ dx,
+                                    long lddx) {
   constexpr int EPV = TypeInfo<T>::EPV;
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const int vi = tid % VP, pl = tid / VP;
+  if (pl >= lanes) return;
   const float invN = 1.f / ((float)HW * (float)cpg);
-  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (long)gridDim.x * blockDim.x) {
-    long pix = v / VP;
-    int vi = (int)(v % VP);
-    int b = (int)(pix / HW);
+  // dx = a*dz - t1 - xh*t2,  xh = (x-mean)*rstd   ==>   dx = a*dz - (k0 + k1*x)
+  float ca[EPV], cb[EPV], k0[EPV], k1[EPV];
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) {
+    int c = vi * EPV + e, g = c / cpg;
+    ca[e] = coef[((long)b * C + c) * 2];
+    cb[e] = coef[((long)b * C + c) * 2 + 1];
+    float mean = mr[((long)b * 32 + g) * 2], rstd = mr[((long)b * 32 + g) * 2 + 1];
+    float t1 = (float)sums[((long)b * 32 + g) * 2] * invN, t2 = (float)sums[((long)b * 32 + g) * 2 + 1] * invN;
+    k1[e] = rstd * t2;
+    k0[e] = t1 - mean * k1[e];
+  }
+  long p0 = (long)blockIdx.x * chunk, p1 = p0 + chunk < HW ? p0 + chunk : HW;
+  const T* xb = x + ((long)b * HW) * ldx + (long)vi * EPV;
+  const T* db = dy + ((long)b * HW) * lddy + (long)vi * EPV;
+  const T* ab = addend ? addend + ((long)b * HW) * lda + (long)vi * EPV : nullptr;
+  T* ob = dx + ((long)b * HW) * lddx + (long)vi * EPV;
+  for (long p = p0 + pl; p < p1; p += lanes) {
     float fx[EPV], fd[EPV], fa[EPV], out[EPV];
-    unpack16<T>(*(const uint4*)(x + pix * ldx + (long)vi * EPV), fx);
-    unpack16<T>(*(const uint4*)(dy + pix * lddy + (long)vi * EPV), fd);
-    if (addend) unpack16<T>(*(const uint4*)(addend + pix * lda + (long)vi * EPV), fa);
+    unpack16<T>(*(const uint4*)(xb + p * ldx), fx);
+    unpack16<T>(*(const uint4*)(db + p * lddy), fd);
+    if (ab) unpack16<T>(*(const uint4*)(ab + p * lda), fa);
 #pragma unroll
     for (int e = 0; e < EPV; ++e) {
-      int c = vi * EPV + e, g = c / cpg;
-      float a = coef[((long)b * C + c) * 2], bb = coef[((long)b * C + c) * 2 + 1];
-      float mean = mr[((long)b * 32 + g) * 2], rstd = mr[((long)b * 32 + g) * 2 + 1];
-      float t1 = (float)sums[((long)b * 32 + g) * 2] * invN, t2 = (float)sums[((long)b * 32 + g) * 2 + 1] * invN;
-      float z = a * fx[e] + bb;
+      float z = ca[e] * fx[e] + cb[e];
       float dz = silu ? fd[e] * silu_grad_f(z) : fd[e];
-      float xh = (fx[e] - mean) * rstd;
-      float r = a * dz - (t1 + xh * t2);
-      out[e] = addend ? r + fa[e] : r;
+      float r = ca[e] * dz - (k0[e] + k1[e] * fx[e]);
+      out[e] = ab ? r + fa[e] : r;
     }
-    *(uint4*)(dx + pix * lddx + (long)vi * EPV) = pack16<T>(out);
+    *(uint4*)(ob + p * lddx) = pack16<T>(out);
   }
 }
 
 int gn_bwd_apply(hipStream_t st, DType dt, const void* x, long ldx, const void* dy, long lddy, const float* coef,
                  const float* mr, const double* sums, int B, long HW, int C, int silu, const void* addend, long lda,
                  void* dx, long lddx) {
-  int EPV = dt == DT_BF16 ? 8 : 4;
-  int VP = C / EPV;
-  long nvec = (long)B * HW * VP;
-  int grid = (int)(nvec / 256 < 1 ? 1 : (nvec / 256 > 8192 ? 8192 : nvec / 256));
-  if (dt == DT_BF16)
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, ldx,
-                       (const bf16_t*)dy, lddy, coef, mr, sums, HW, C, VP, C / 32, nvec, silu, (const bf16_t*)addend,
-                       lda, (bf16_t*)dx, lddx);
-  else
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, ldx,
-                       (const float*)dy, lddy, coef, mr, sums, HW, C, VP, C / 32, nvec, silu, (const float*)addend,
-                       lda, (float*)dx, lddx);
+  long chunk = pick_chunk_stream(HW, B);
+  dim3 grid(cdiv(HW, chunk), B);
+  if (dt == DT_BF16) {
+    GnGeom g = gn_geom<bf16_t>(C);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, grid, dim3(g.nthreads), 0, st, (const bf16_t*)x, ldx,
+                       (const bf16_t*)dy, lddy, coef, mr, sums, HW, C, g.VP, g.lanes, g.cpg, chunk, silu,
+                       (const bf16_t*)addend, lda, (bf16_t*)dx, lddx);
+  } else {
+    GnGeom g = gn_geom<float>(C);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid, dim3(g.nthreads), 0, st, (const float*)x, ldx,
+                       (const float*)dy, lddy, coef, mr, sums, HW, C, g.VP, g.lanes, g.cpg, chunk, silu,
+                       (const float*)addend, lda, (float*)dx, lddx);
+  }
   KDIP_LAUNCH_CHECK();
   return KDIP_OK;
 }

@@ -250,14 +250,14 @@ int gn_backward(Ctx& c, const void* x, long ldx, const void* dy, long lddy, cons
 int conv_f(Ctx& c, const ConvW& w, const void* x, long ldx, int B, int H, int W, void* y, long ldy, const void* res,
            long ldr, int out_f32) {
   bool dry = c.dry;
-  RUN(conv_forward(c.st, c.dt, w.ntaps, x, ldx, B, H, W, w.cin_pad, w.wf, w.bias, w.cout, y, ldy, res, ldr, out_f32, 1.f));
+  RUN(conv_forward(c.st, c.dt, w.ntaps, x, ldx, B, H, W, w.cin_pad, w.wf, w.bias, w.cout, y, ldy, res, ldr, out_f32, 1.f, w.cin));
   return KDIP_OK;
 }
 // input-gradient: x here is dL/d(out) with >= cin_pad_b channels available (zero padded when cout % 32 != 0)
 int conv_b(Ctx& c, const ConvW& w, const void* g, long ldg, int B, int H, int W, void* y, long ldy, const void* res,
            long ldr, int out_f32) {
   bool dry = c.dry;
-  RUN(conv_forward(c.st, c.dt, w.ntaps, g, ldg, B, H, W, w.cin_pad_b, w.wb, nullptr, w.cin, y, ldy, res, ldr, out_f32, 1.f));
+  RUN(conv_forward(c.st, c.dt, w.ntaps, g, ldg, B, H, W, w.cin_pad_b, w.wb, nullptr, w.cin, y, ldy, res, ldr, out_f32, 1.f, w.cout));
   return KDIP_OK;
 }
 }  // namespace

@@ -85,29 +85,35 @@ def sample_euler(model, x, sigmas, extra_args=None, callback=None, disable=None,
     return x
 
 
+def heun_step(model, x, sig, i, extra_args=None, callback=None, sigmas=None, s_churn=0., s_tmin=0.,
+              s_tmax=float('inf'), s_noise=1.):
+    """One iteration i of sample_heun's loop on the host-side fp32 schedule `sig` (2 model calls,
+    1 for the last step).  Exposed so a harness can time individual sampler steps."""
+    extra_args = {} if extra_args is None else extra_args
+    lib = L.load()
+    n = x.numel()
+    x, sigma_hat = _churn(x, sig, i, s_churn, s_tmin, s_tmax, s_noise, lib)
+    denoised = model(x, _sigma_vec(x, sigma_hat), **extra_args).contiguous()
+    if callback is not None:
+        callback({'x': x, 'i': i, 'sigma': (sigmas if sigmas is not None else sig)[i], 'sigma_hat': sigma_hat,
+                  'denoised': denoised})
+    dt = sig[i + 1] - sigma_hat
+    xn = torch.empty_like(x)
+    if sig[i + 1] == 0:
+        L.check(lib.kdip_sampler_euler(L.stream(), L.ptr(x), L.ptr(denoised), float(sigma_hat), float(dt), n, L.ptr(xn)))
+        return xn
+    x_2 = torch.empty_like(x)
+    L.check(lib.kdip_sampler_euler(L.stream(), L.ptr(x), L.ptr(denoised), float(sigma_hat), float(dt), n, L.ptr(x_2)))
+    denoised_2 = model(x_2, _sigma_vec(x, sig[i + 1]), **extra_args).contiguous()
+    L.check(lib.kdip_sampler_heun(L.stream(), L.ptr(x), L.ptr(denoised), L.ptr(x_2), L.ptr(denoised_2),
+                                  float(sigma_hat), float(sig[i + 1]), float(dt), n, L.ptr(xn)))
+    return xn
+
+
 def sample_heun(model, x, sigmas, extra_args=None, callback=None, disable=None, s_churn=0., s_tmin=0.,
                 s_tmax=float('inf'), s_noise=1.):
     """Algorithm 2 (Heun steps) from Karras et al. (2022); the last step (sigma -> 0) is Euler."""
-    extra_args = {} if extra_args is None else extra_args
-    lib = L.load()
     x, sig = _prep(x, sigmas)
-    n = x.numel()
     for i in _trange(len(sig) - 1, disable):
-        x, sigma_hat = _churn(x, sig, i, s_churn, s_tmin, s_tmax, s_noise, lib)
-        denoised = model(x, _sigma_vec(x, sigma_hat), **extra_args).contiguous()
-        if callback is not None:
-            callback({'x': x, 'i': i, 'sigma': sigmas[i], 'sigma_hat': sigma_hat, 'denoised': denoised})
-        dt = sig[i + 1] - sigma_hat
-        if sig[i + 1] == 0:
-            xn = torch.empty_like(x)
-            L.check(lib.kdip_sampler_euler(L.stream(), L.ptr(x), L.ptr(denoised), float(sigma_hat), float(dt), n, L.ptr(xn)))
-            x = xn
-        else:
-            x_2 = torch.empty_like(x)
-            L.check(lib.kdip_sampler_euler(L.stream(), L.ptr(x), L.ptr(denoised), float(sigma_hat), float(dt), n, L.ptr(x_2)))
-            denoised_2 = model(x_2, _sigma_vec(x, sig[i + 1]), **extra_args).contiguous()
-            xn = torch.empty_like(x)
-            L.check(lib.kdip_sampler_heun(L.stream(), L.ptr(x), L.ptr(denoised), L.ptr(x_2), L.ptr(denoised_2),
-                                          float(sigma_hat), float(sig[i + 1]), float(dt), n, L.ptr(xn)))
-            x = xn
+        x = heun_step(model, x, sig, i, extra_args, callback, sigmas, s_churn, s_tmin, s_tmax, s_noise)
     return x

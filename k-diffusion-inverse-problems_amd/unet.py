@@ -155,3 +155,101 @@ def create_model_and_diffusion(image_size=256, num_channels=128, num_res_blocks=
                       attention_resolutions=attention_resolutions, channel_mult=channel_mult,
                       num_head_channels=num_head_channels, out_channels=6 if learn_sigma else 3, dtype=dtype, device=device)
     return model, GaussianDiffusionTables(diffusion_steps)
+
+
+# ---------------------------------------------------------------- synthetic weights ----
+def _plan(image_size, model_channels, num_res_blocks, attention_ds, channel_mult, in_channels=3):
+    """Block list of UNetModel.__init__ (guided_diffusion/unet.py:482-619): per block a list of
+    ('conv', cin, cout) | ('res', cin, cout) | ('attn', ch)."""
+    mc = model_channels
+    ch = int(channel_mult[0] * mc)
+    inp, chans, ds = [[("conv", in_channels, ch)]], [ch], 1
+    for level, mult in enumerate(channel_mult):
+        for _ in range(num_res_blocks):
+            layers = [("res", ch, int(mult * mc))]
+            ch = int(mult * mc)
+            if ds in attention_ds:
+                layers.append(("attn", ch))
+            inp.append(layers); chans.append(ch)
+        if level != len(channel_mult) - 1:
+            inp.append([("res", ch, ch)]); chans.append(ch); ds *= 2
+    mid = [("res", ch, ch), ("attn", ch), ("res", ch, ch)]
+    out = []
+    for level, mult in list(enumerate(channel_mult))[::-1]:
+        for i in range(num_res_blocks + 1):
+            ich = chans.pop()
+            layers = [("res", ch + ich, int(mc * mult))]
+            ch = int(mc * mult)
+            if ds in attention_ds:
+                layers.append(("attn", ch))
+            if level and i == num_res_blocks:
+                layers.append(("res", ch, ch)); ds //= 2
+            out.append(layers)
+    return inp, mid, out, ch
+
+
+def state_dict_shapes(image_size=256, model_channels=128, num_res_blocks=1, attention_resolutions="16", channel_mult="",
+                      out_channels=6, out_cov=False):
+    """Ordered {reference state_dict key: shape} and the set of keys `zero_module` zeroes."""
+    cm = _channel_mult_default(image_size) if channel_mult in ("", None, ()) else tuple(channel_mult)
+    ads = tuple(image_size // int(r) for r in str(attention_resolutions).split(","))
+    mc, ted = model_channels, model_channels * 4
+    shapes, zero = {}, set()
+
+    def add(k, s, z=False):
+        shapes[k] = tuple(s)
+        if z:
+            zero.add(k)
+    add("time_embed.0.weight", (ted, mc)); add("time_embed.0.bias", (ted,))
+    add("time_embed.2.weight", (ted, ted)); add("time_embed.2.bias", (ted,))
+
+    def add_layers(prefix, layers):
+        for j, Lr in enumerate(layers):
+            p = f"{prefix}.{j}"
+            if Lr[0] == "conv":
+                add(f"{p}.weight", (Lr[2], Lr[1], 3, 3)); add(f"{p}.bias", (Lr[2],))
+            elif Lr[0] == "res":
+                _, cin, cout = Lr
+                add(f"{p}.in_layers.0.weight", (cin,)); add(f"{p}.in_layers.0.bias", (cin,))
+                add(f"{p}.in_layers.2.weight", (cout, cin, 3, 3)); add(f"{p}.in_layers.2.bias", (cout,))
+                add(f"{p}.emb_layers.1.weight", (2 * cout, ted)); add(f"{p}.emb_layers.1.bias", (2 * cout,))
+                add(f"{p}.out_layers.0.weight", (cout,)); add(f"{p}.out_layers.0.bias", (cout,))
+                add(f"{p}.out_layers.3.weight", (cout, cout, 3, 3), True); add(f"{p}.out_layers.3.bias", (cout,), True)
+                if cin != cout:
+                    add(f"{p}.skip_connection.weight", (cout, cin, 1, 1)); add(f"{p}.skip_connection.bias", (cout,))
+            else:
+                c = Lr[1]
+                add(f"{p}.norm.weight", (c,)); add(f"{p}.norm.bias", (c,))
+                add(f"{p}.qkv.weight", (3 * c, c, 1)); add(f"{p}.qkv.bias", (3 * c,))
+                add(f"{p}.proj_out.weight", (c, c, 1), True); add(f"{p}.proj_out.bias", (c,), True)
+    inp, mid, out, ch = _plan(image_size, mc, num_res_blocks, ads, cm)
+    for i, layers in enumerate(inp):
+        add_layers(f"input_blocks.{i}", layers)
+    add_layers("middle_block", mid)
+    for i, layers in enumerate(out):
+        add_layers(f"output_blocks.{i}", layers)
+    add("out.0.weight", (ch,)); add("out.0.bias", (ch,))
+    add("out.2.weight", (out_channels, ch, 3, 3), True); add("out.2.bias", (out_channels,), True)
+    if out_cov:
+        add("out_cov.weight", (6, ch, 1, 1)); add("out_cov.bias", (6,))
+    return shapes, zero
+
+
+def synthetic_state_dict(seed=0, out_cov=False, **cfg):
+    """Seeded random-init weights of the named architecture (no checkpoint is obtainable offline):
+    uniform(+-1/sqrt(fan_in)) like PyTorch's default; zero-initialised modules re-drawn N(0, 0.02^2)
+    so the network output is not identically zero; GroupNorm affine = 1 + 0.1 n, 0.1 n."""
+    g = torch.Generator().manual_seed(seed)
+    shapes, zero = state_dict_shapes(out_cov=out_cov, **cfg)
+    sd = {}
+    for k, s in shapes.items():
+        if ".in_layers.0." in k or ".out_layers.0." in k or ".norm." in k or k.startswith("out.0."):
+            r = torch.randn(s, generator=g) * 0.1
+            sd[k] = (1.0 + r) if k.endswith("weight") else r
+        elif k in zero:
+            sd[k] = torch.randn(s, generator=g) * 0.02
+        else:
+            wshape = s if k.endswith("weight") else shapes[k[:-4] + "weight"]
+            fan_in = int(np.prod(wshape[1:]))
+            sd[k] = (torch.rand(s, generator=g) * 2 - 1) * (1.0 / math.sqrt(fan_in))
+    return sd

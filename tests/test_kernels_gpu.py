@@ -36,6 +36,9 @@ CONV_CASES = [
     (2, 64, 192, 8, 8, 1),
     (5, 128, 256, 1, 1, 1),
     (1, 32, 32, 64, 64, 1),
+    (2, 32, 128, 256, 256, 9),     # large-M shapes select the 256x128 block tile
+    (2, 64, 256, 256, 256, 1),
+    (32, 64, 128, 64, 64, 9),
 ]
 
 
