@@ -190,6 +190,8 @@ def main():
         n = lib.kdip_profile_num_classes()
         ms = (C.c_double * n)(); fl = (C.c_double * n)(); by = (C.c_double * n)(); la = (C.c_long * n)()
         L.check(lib.kdip_profile_report(ms, fl, by, la))
+        if os.environ.get("KDIP_PROFILE_DUMP"):
+            L.check(lib.kdip_profile_dump(os.environ["KDIP_PROFILE_DUMP"].encode()))
         L.check(lib.kdip_profile_enable(0))
         k = max(range(n), key=lambda j: ms[j])
         tflops = fl[k] / (ms[k] * 1e-3) / 1e12 if ms[k] > 0 else 0.0

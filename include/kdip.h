@@ -152,6 +152,8 @@ int kdip_profile_enable(int on);
 int kdip_profile_num_classes(void);
 const char* kdip_profile_class_name(int cls);
 int kdip_profile_report(double* ms, double* flops, double* bytes, long* launches);
+/* writes one CSV row per recorded launch (class, shape, algorithmic GFLOP / MB, microseconds). */
+int kdip_profile_dump(const char* path);
 
 /* ------------------------------------------------------------------ low-level test hooks
  * (exercised by tests/ to localise kernel bugs; NHWC tensors of the UNet storage dtype) */

@@ -14,12 +14,12 @@ int set_error(int code, const char* fmt, ...) {
 }
 
 bool g_prof_on = false;
-struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; };
+struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; const char* tag; long d[4]; };
 static std::vector<ProfRec> g_recs;
 static ProfRec g_cur;
-void prof_begin(hipStream_t st, int cls, double flops, double bytes) {
+void prof_begin(hipStream_t st, int cls, double flops, double bytes, const char* tag, long d0, long d1, long d2, long d3) {
   if (!g_prof_on) return;
-  g_cur.cls = cls; g_cur.flops = flops; g_cur.bytes = bytes;
+  g_cur.cls = cls; g_cur.flops = flops; g_cur.bytes = bytes; g_cur.tag = tag; g_cur.d[0] = d0; g_cur.d[1] = d1; g_cur.d[2] = d2; g_cur.d[3] = d3;
   (void)hipEventCreate(&g_cur.a); (void)hipEventCreate(&g_cur.b);
   (void)hipEventRecord(g_cur.a, st);
 }
@@ -38,6 +38,20 @@ int kdip_profile_enable(int on) {
   for (auto& r : g_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   g_recs.clear();
   g_prof_on = on != 0;
+  return 0;
+}
+int kdip_profile_dump(const char* path) {
+  using namespace kdip;
+  FILE* f = fopen(path, "w");
+  if (!f) return set_error(KDIP_ERR_ARG, "cannot open %s", path);
+  fprintf(f, "class,tag,d0,d1,d2,d3,gflop,mbytes,us\n");
+  for (auto& r : g_recs) {
+    (void)hipEventSynchronize(r.b);
+    float t = 0; (void)hipEventElapsedTime(&t, r.a, r.b);
+    fprintf(f, "%s,%s,%ld,%ld,%ld,%ld,%.3f,%.3f,%.2f\n", kClassNames[r.cls], r.tag ? r.tag : "", r.d[0], r.d[1], r.d[2], r.d[3],
+            r.flops / 1e9, r.bytes / 1e6, t * 1e3);
+  }
+  fclose(f);
   return 0;
 }
 int kdip_profile_num_classes(void) { return kdip::PC_COUNT; }

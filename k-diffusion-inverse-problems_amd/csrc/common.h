@@ -119,7 +119,7 @@ inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 enum ProfClass { PC_CONV3_128x128 = 0, PC_CONV3_128x64, PC_CONV3_128x32, PC_CONV1_128x128, PC_CONV1_128x64,
                  PC_CONV1_128x32, PC_COUNT };
 extern bool g_prof_on;
-void prof_begin(hipStream_t st, int cls, double flops, double bytes);
+void prof_begin(hipStream_t st, int cls, double flops, double bytes, const char* tag = nullptr, long d0 = 0, long d1 = 0, long d2 = 0, long d3 = 0);
 void prof_end(hipStream_t st);
 
 }  // namespace kdip

@@ -53,21 +53,25 @@ struct ConvParams {
   int out_f32;                    // store fp32 regardless of T
   float alpha;                    // output scale (applied before bias)
   int cin_real;                   // un-padded input channels (profiling / algorithmic FLOPs only)
+  int vec_epilogue;               // LDS-transposed 4-channel-per-lane stores
 };
 
-constexpr int KC = 32;            // input channels per LDS chunk
+constexpr int KC = 32;            // input channels per B-pipeline stage (one tap of one 32-channel sub-chunk)
 
-template <typename T, int NTAPS, int WAVES_M, int WAVES_N, int MT, int NT>
+// SUBS = 32-channel sub-chunks staged in LDS per barrier (1 for 3x3; up to 4 for 1x1 so a barrier
+// covers 32 MFMAs per wave instead of 8).
+template <typename T, int NTAPS, int WAVES_M, int WAVES_N, int MT, int NT, int SUBS>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(ConvParams p) {
   constexpr int NTHREADS = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * MT * 32;
   constexpr int BN = WAVES_N * NT * 32;
   constexpr int KSTEP = Mma<T>::KSTEP;
-  constexpr int KS = KC / KSTEP;                       // k-steps per chunk
-  constexpr int PIXB = KC * (int)sizeof(T) + 16;       // padded LDS pixel stride (bytes)
-  constexpr int VPP = KC * (int)sizeof(T) / 16;        // 16-byte vectors per pixel-chunk
+  constexpr int KS = KC / KSTEP;                       // k-steps per 32-channel sub-chunk
+  constexpr int KCH = KC * SUBS;                       // channels per LDS stage
+  constexpr int PIXB = KCH * (int)sizeof(T) + 16;      // padded LDS pixel stride (bytes)
+  constexpr int VPP = KCH * (int)sizeof(T) / 16;       // 16-byte vectors per staged pixel
   constexpr int HALO = (NTAPS == 9) ? 1 : 0;
-  constexpr int MAXPIX = (BM == 256) ? 400 : 256;      // halo pixels: 18x18 (one 16x16 patch) or 4 x 10x10
+  constexpr int MAXPIX = (NTAPS == 1) ? BM : ((BM == 256) ? 400 : 256);
   constexpr int MAXV = (MAXPIX * VPP + NTHREADS - 1) / NTHREADS;   // staged 16-byte vectors per thread
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(ConvP
   const int mtile = bid / nblkN, ntb = bid % nblkN;
   // M tile -> (image group, patch origin)
   const int tpi = p.tilesX * p.tilesY;                 // tiles per image (1 when TB>1)
-  const int b0 = (mtile / tpi) * p.TB;
+  const int img0 = (mtile / tpi) * p.TB;
   const int trem = mtile % tpi;
   const int y0 = (trem / p.tilesX) * p.TH, x0 = (trem % p.tilesX) * p.TW;
   const int HW_ = p.TW + 2 * HALO, HH_ = p.TH + 2 * HALO;
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(ConvP
     if (pix < npix) {
       int tb = pix / (HH_ * HW_), rr = pix % (HH_ * HW_);
       int hy = rr / HW_, hx = rr % HW_;
-      int gy = y0 + hy - HALO, gx = x0 + hx - HALO, gb = b0 + tb;
+      int gy = y0 + hy - HALO, gx = x0 + hx - HALO, gb = img0 + tb;
       loff[i] = pix * PIXB + sub * 16;
       if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && gb < p.B)
         goff[i] = (((long)gb * p.H + gy) * p.W + gx) * p.ldx + sub * (16 / (int)sizeof(T));
@@ -138,13 +142,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(ConvP
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-  const int nchunks = p.Cin / KC;
+  const int nchunks = p.Cin / KCH;
   uint4 areg[MAXV];
   auto stage_load = [&](int c) {
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       areg[i] = make_uint4(0, 0, 0, 0);
-      if (goff[i] >= 0) areg[i] = *(const uint4*)(xin + goff[i] + (long)c * KC);
+      if (goff[i] >= 0) areg[i] = *(const uint4*)(xin + goff[i] + (long)c * KCH);
     }
   };
   auto stage_write = [&](int buf) {
@@ -157,16 +161,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(ConvP
   stage_write(0);
   __syncthreads();
 
-  // B fragments are software-pipelined two stages (= taps) ahead in registers; a stage index past
-  // the end is clamped to the last stage (one redundant L2 hit) so the loop body has no branches.
-  const int nstages = nchunks * NTAPS;
+  // B fragments are software-pipelined two stages (= one tap of one 32-channel sub-chunk) ahead in
+  // registers; a stage index past the end is clamped to the last stage (one redundant L2 hit) so the
+  // loop body has no branches.
+  const int nstages = nchunks * SUBS * NTAPS;
   auto load_b = [&](uint4 (&dst)[KS][NT], int stage) {
     stage = stage < nstages ? stage : nstages - 1;
-    const int cc = stage / NTAPS, tp = stage - cc * NTAPS;
+    const int c32 = stage / NTAPS, tp = stage - c32 * NTAPS;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) dst[ks][nt] = *bptr(tp, (long)cc * KS + ks, nt);
+      for (int nt = 0; nt < NT; ++nt) dst[ks][nt] = *bptr(tp, (long)c32 * KS + ks, nt);
   };
   uint4 bq0[KS][NT], bq1[KS][NT], bq2[KS][NT];
   load_b(bq0, 0);
@@ -177,30 +182,89 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(ConvP
     if (c + 1 < nchunks) stage_load(c + 1);
     const unsigned char* abuf = smem + buf * abuf_bytes;
 #pragma unroll
-    for (int tap = 0; tap < NTAPS; ++tap) {
-      load_b(bq2, c * NTAPS + tap + 2);
-      const int toff = (NTAPS == 9) ? ((tap / 3) * HW_ + (tap % 3)) * PIXB : 0;
+    for (int sub = 0; sub < SUBS; ++sub) {
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        uint4 a[MT];
+      for (int tap = 0; tap < NTAPS; ++tap) {
+        load_b(bq2, (c * SUBS + sub) * NTAPS + tap + 2);
+        const int toff = ((NTAPS == 9) ? ((tap / 3) * HW_ + (tap % 3)) * PIXB : 0) + sub * KC * (int)sizeof(T);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a[mt] = *(const uint4*)(abuf + abase[mt] + toff + ks * 32);
+        for (int ks = 0; ks < KS; ++ks) {
+          uint4 a[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+          for (int mt = 0; mt < MT; ++mt) a[mt] = *(const uint4*)(abuf + abase[mt] + toff + ks * 32);
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) Mma<T>::run(a[mt], bq0[ks][nt], acc[mt][nt]);
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) Mma<T>::run(a[mt], bq0[ks][nt], acc[mt][nt]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) { bq0[ks][nt] = bq1[ks][nt]; bq1[ks][nt] = bq2[ks][nt]; }
       }
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) { bq0[ks][nt] = bq1[ks][nt]; bq1[ks][nt] = bq2[ks][nt]; }
     }
     if (c + 1 < nchunks) stage_write(buf ^ 1);
     __syncthreads();
   }
 
-  // ---- epilogue: bias + residual + cast, NHWC store (32 lanes = 32 consecutive channels)
+  // ---- epilogue: alpha, bias, residual, cast.
   const T* res = (const T*)p.res;
+  if (p.vec_epilogue) {
+    // Fast path (Cout % 4 == 0): each wave transposes its fp32 accumulators through LDS so that a
+    // lane owns 4 consecutive channels of one pixel -> 8/16-byte global stores on full 128-byte+
+    // pixel rows (the MFMA layout alone gives 2-byte stores: store-issue bound on short-K layers).
+    constexpr int RS = NT * 32 * 4 + 16;               // fp32 row stride of the per-wave region
+    constexpr int LPR = NT * 8;                        // lanes (4-channel vectors) per pixel row
+    constexpr int RPI = 64 / LPR;                      // pixel rows per pass
+    unsigned char* creg = smem + wave * 32 * RS;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = (nt0 + nt) * 32 + (lane & 31);
+        const float bv = (n < p.Cout && p.bias) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          *(float*)(creg + row * RS + (nt * 32 + (lane & 31)) * 4) = acc[mt][nt][r] * p.alpha + bv;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+      for (int it = 0; it < 32 / RPI; ++it) {
+        const int row = it * RPI + lane / LPR, vec = lane % LPR;
+        const int m = (wm * MT + mt) * 32 + row;
+        const int tb = m >> p.lgTHW, rr = m & ((1 << p.lgTHW) - 1);
+        const int ty = rr >> p.lgTW, tx = rr & (p.TW - 1);
+        const int gb = img0 + tb, n = nt0 * 32 + vec * 4;
+        float4 v = *(const float4*)(creg + row * RS + vec * 16);
+        if (gb < p.B && n < p.Cout) {
+          const long pix = ((long)gb * p.H + (y0 + ty)) * p.W + (x0 + tx);
+          if (res) {
+            if (sizeof(T) == 2) {
+              uint2 rv = *(const uint2*)(res + pix * p.ldr + n);
+              v.x += __uint_as_float(rv.x << 16); v.y += __uint_as_float(rv.x & 0xffff0000u);
+              v.z += __uint_as_float(rv.y << 16); v.w += __uint_as_float(rv.y & 0xffff0000u);
+            } else {
+              float4 rv = *(const float4*)(res + pix * p.ldr + n);
+              v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+            }
+          }
+          if (p.out_f32 || sizeof(T) == 4) {
+            *(float4*)((float*)p.y + pix * p.ldy + n) = v;
+          } else {
+            uint2 o;
+            o.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+            o.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+            *(uint2*)((bf16_t*)p.y + pix * p.ldy + n) = o;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    return;
+  }
+  // Generic path (ragged Cout, e.g. the 6- and 3-channel heads): MFMA layout, scalar stores.
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int n = (nt0 + nt) * 32 + (lane & 31);
@@ -213,7 +277,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(ConvP
         int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         int tb = m >> p.lgTHW, rr = m & ((1 << p.lgTHW) - 1);
         int ty = rr >> p.lgTW, tx = rr & (p.TW - 1);
-        int gb = b0 + tb;
+        int gb = img0 + tb;
         if (!nok || gb >= p.B) continue;
         long pix = ((long)gb * p.H + (y0 + ty)) * p.W + (x0 + tx);
         float v = acc[mt][nt][r] * p.alpha + bv;
@@ -225,10 +289,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(ConvP
   }
 }
 
-template <typename T, int NTAPS, int WAVES_M, int WAVES_N, int MT, int NT>
-static int launch_cfg(ConvParams& p, hipStream_t st) {
+template <typename T, int NTAPS, int WAVES_M, int WAVES_N, int MT, int NT, int SUBS>
+static int launch_cfg2(ConvParams& p, hipStream_t st) {
   constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32;
-  constexpr int PIXB = KC * (int)sizeof(T) + 16;
+  constexpr int PIXB = KC * SUBS * (int)sizeof(T) + 16;
   constexpr int HALO = (NTAPS == 9) ? 1 : 0;
   int TW = p.W < 16 ? p.W : 16;
   int TH = p.H < BM / TW ? p.H : BM / TW;
@@ -243,21 +307,46 @@ static int launch_cfg(ConvParams& p, hipStream_t st) {
   p.tilesX = p.W / TW; p.tilesY = p.H / TH;
   p.mtiles = cdiv(p.B, TB) * p.tilesX * p.tilesY;
   int npix = TB * (TH + 2 * HALO) * (TW + 2 * HALO);
-  if (npix > (BM == 256 ? 400 : 256)) return set_error(KDIP_ERR_UNSUPPORTED, "conv: halo patch too large (%d px)", npix);
+  if (npix > ((NTAPS == 1) ? BM : (BM == 256 ? 400 : 256)))
+    return set_error(KDIP_ERR_UNSUPPORTED, "conv: halo patch too large (%d px)", npix);
   size_t lds = (size_t)2 * npix * PIXB;
+  const bool osz4 = p.out_f32 || sizeof(T) == 4;
+  p.vec_epilogue = (p.Cout % 4 == 0) && (p.ldy % 4 == 0) && (!p.res || p.ldr % 4 == 0) &&
+                   ((uintptr_t)p.y % (osz4 ? 16 : 8) == 0) && (!p.res || (uintptr_t)p.res % (sizeof(T) == 2 ? 8 : 16) == 0);
+  if (p.vec_epilogue) {
+    size_t cl = (size_t)WAVES_M * WAVES_N * 32 * (NT * 32 * 4 + 16);
+    if (cl > lds) lds = cl;
+  }
   int nblkN = cdiv(p.ntilesN * 32, BN);
   long grid = (long)p.mtiles * nblkN;
-  auto kern = conv_igemm_kernel<T, NTAPS, WAVES_M, WAVES_N, MT, NT>;
+  auto kern = conv_igemm_kernel<T, NTAPS, WAVES_M, WAVES_N, MT, NT, SUBS>;
   if (g_prof_on) {
     const int cls = (NTAPS == 9 ? 0 : 3) + (BN == 128 ? 0 : (BN == 64 ? 1 : 2));
     const double px = (double)p.B * p.H * p.W;
     prof_begin(st, cls, 2.0 * px * p.cin_real * p.Cout * NTAPS,
-               px * (p.cin_real + p.Cout) * sizeof(T) + (double)NTAPS * p.cin_real * p.Cout * sizeof(T));
+               px * (p.cin_real + p.Cout) * sizeof(T) + (double)NTAPS * p.cin_real * p.Cout * sizeof(T), "conv", p.B, p.H, p.cin_real, p.Cout);
+  }
+  if (lds > 48 * 1024) {
+    static size_t granted = 0;          // per instantiation: raise the dynamic-LDS cap once
+    if (lds > granted) {
+      KDIP_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024)));
+      granted = 96 * 1024;
+    }
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES_M * WAVES_N * 64), lds, st, p);
   prof_end(st);
   KDIP_LAUNCH_CHECK();
   return KDIP_OK;
+}
+
+template <typename T, int NTAPS, int WAVES_M, int WAVES_N, int MT, int NT>
+static int launch_cfg(ConvParams& p, hipStream_t st) {
+  if (NTAPS == 1) {
+    // 1x1 / linear: stage up to 128 channels per barrier
+    if (sizeof(T) == 2 && p.Cin % 128 == 0) return launch_cfg2<T, NTAPS, WAVES_M, WAVES_N, MT, NT, (NTAPS == 1 ? 4 : 1)>(p, st);
+    if (sizeof(T) == 2 && p.Cin % 64 == 0) return launch_cfg2<T, NTAPS, WAVES_M, WAVES_N, MT, NT, (NTAPS == 1 ? 2 : 1)>(p, st);
+  }
+  return launch_cfg2<T, NTAPS, WAVES_M, WAVES_N, MT, NT, 1>(p, st);
 }
 
 template <typename T, int NTAPS>
