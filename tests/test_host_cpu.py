@@ -1,0 +1,172 @@
+"""CPU (-m "not gpu"): host-side logic of the product package against the oracle, the C-ABI
+library loads and exports every symbol include/kdip.h declares, no compute without a GPU, and
+the N>1 sharding/gather path under gloo (world_size 2)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import kdip_amd._lib as L
+    lib = L.load()
+    hdr = open(os.path.join(ROOT, "include", "kdip.h")).read()
+    declared = set(re.findall(r"\b(kdip_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(L.SIGNATURES), (declared ^ set(L.SIGNATURES))
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.kdip_version() >= 100
+    assert lib.kdip_profile_num_classes() > 0
+
+
+def test_no_cpu_fallback():
+    """Without a GPU every compute entry point of the product fails loudly."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import kdip_amd._lib as L
+    import kdip_amd.unet as ku
+    import kdip_amd.measurements as km
+    import kdip_amd.sampling as ks
+    with pytest.raises(L.KdipError):
+        ku.UNetModel(image_size=64, model_channels=32, attention_resolutions="32", channel_mult=(1, 2))
+    with pytest.raises(L.KdipError):
+        km.get_operator("gaussian_blur", device="cpu", in_shape=(1, 3, 64, 64), kernel_size=61, intensity=3.0, sigma_s=0.05)
+    with pytest.raises(L.KdipError):
+        ks.sample_euler(lambda x, s: x, torch.zeros(1, 3, 8, 8), ks.get_sigmas_karras(4, 0.01, 80))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "k-diffusion-inverse-problems_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in re.sub(r"#.*", "", src).replace("oracle restatement", ""), fn
+
+
+def test_schedule_and_tables_match_oracle(gold):
+    import kdip_amd.sampling as ks
+    import kdip_amd.external as ke
+    import kdip_amd.unet as ku
+    from oracle import tables as otab
+    g = gold("tables")
+    assert torch.equal(ks.get_sigmas_karras(100, 0.01, 80), torch.from_numpy(g["sigmas100"]))
+    D, O = ku.GaussianDiffusionTables(), otab.DiffusionTables()
+    for nm in ("alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped", "posterior_mean_coef1",
+               "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "log_betas"):
+        assert np.array_equal(getattr(D, nm), getattr(O, nm)), nm
+    den = ke.OpenAIDenoiser(None, D)
+    probe = torch.from_numpy(g["probe"])
+    assert torch.equal(den.sigma_to_t(probe), torch.from_numpy(g["t_frac"]))
+    assert torch.equal(den.sigma_to_t(probe).long(), torch.from_numpy(g["t_floor"]))
+    s = torch.tensor([0.3, 0.3]); s._kdip_host_value = 0.3
+    assert torch.equal(den.sigma_to_t(s), O.sigma_to_t(torch.tensor([0.3, 0.3])))
+    c_out, c_in = den.get_scalings(torch.tensor([2.0]))
+    assert float(c_out) == -2.0 and abs(float(c_in) - 5 ** -0.5) < 1e-7
+
+
+def test_synthetic_weights_and_plan_match_oracle():
+    import kdip_amd.unet as ku
+    from oracle import unet as ou
+    a = ku.synthetic_state_dict(seed=0, out_cov=True, image_size=64, model_channels=32, num_res_blocks=1,
+                                attention_resolutions="32", channel_mult=(1, 2))
+    b = ou.init_state_dict(ou.UNetConfig(**ou.TINY), seed=0, out_cov=True)
+    assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a)
+    for cfg_p, cfg_o in ((ku.FFHQ_CONFIG, ou.FFHQ), (ku.IMAGENET_CONFIG, ou.IMAGENET)):
+        sp, zp = ku.state_dict_shapes(**cfg_p)
+        so, zo = ou.param_shapes(ou.UNetConfig(**cfg_o))
+        assert sp == so and zp == zo
+    n = sum(int(np.prod(s)) for s in ku.state_dict_shapes(**ku.FFHQ_CONFIG)[0].values())
+    assert n == 93563910
+
+
+def test_mask_generator_bit_exact(gold):
+    import kdip_amd.measurements as km
+    g = gold("operators")
+    np.random.seed(0)
+    m = km.MaskGenerator(mask_type="random", mask_prob_range=(0.5, 0.5), image_size=256)(torch.empty(1, 3, 256, 256))
+    bits = np.unpackbits(g["inpainting.mask256_bits"]).reshape(256, 256)
+    assert np.array_equal(m[0, 0].numpy().astype(np.uint8), bits)
+    assert torch.equal(m[0, 0], m[0, 1]) and torch.equal(m[0, 0], m[0, 2])
+    with pytest.raises(NotImplementedError):
+        km.MaskGenerator(mask_type="box", mask_len_range=(128, 129))(torch.empty(1, 3, 256, 256))
+
+
+def test_resize_tables_match_oracle():
+    import kdip_amd.measurements as km
+    from oracle import operators as oops
+    for n_in, n_out in ((256, 64), (64, 16)):
+        w, f = km.cubic_resize_tables(n_in, n_out, 0.25)
+        wo, fo = oops.resizer_contributions(n_in, n_out, 0.25)
+        assert w.shape == wo.shape == (n_out, 16)
+        assert np.array_equal(f, fo.astype(np.int32))
+        assert np.array_equal(w, wo.astype(np.float32))
+
+
+def test_registries():
+    import kdip_amd.measurements as km
+    import kdip_amd.condition as kc
+    import kdip_amd.transforms as kt
+    assert set(km.__OPERATOR__) == {"motion_blur", "gaussian_blur", "super_resolution", "inpainting"}
+    assert set(kc.__MAT_SOLVER__) == set(km.__OPERATOR__)
+    assert set(kt.__OT__) == {"dct", "dwt"}
+    with pytest.raises(NameError):
+        km.get_operator("nope")
+    with pytest.raises(NameError):
+        km.register_operator("inpainting")(type("X", (), {}))
+    f = kc.register_mat_solver("custom_op")(lambda *a, **k: None)
+    assert kc.__MAT_SOLVER__.pop("custom_op") is f
+
+
+def test_shard_range_and_compute_features_single():
+    from kdip_amd.evaluation import shard_range, compute_features, DistEnv, psnr
+    assert [shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
+    assert shard_range(128, 7, 8) == (112, 128)
+    env = DistEnv(init=False)
+    env.world_size = 1
+    calls = []
+
+    def sample_fn(n):
+        calls.append(n)
+        return torch.full((n, 3, 4, 4), float(len(calls)))
+    out = compute_features(env, sample_fn, lambda x: x, 5, 2)
+    assert out.shape[0] == 5 and calls == [2, 2, 1]
+    a = torch.zeros(1, 3, 4, 4); b = torch.full((1, 3, 4, 4), 0.2)
+    assert abs(float(psnr(a, b)) - 20.0) < 1e-4
+
+
+WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, sys.argv[1])
+from kdip_amd.evaluation import DistEnv, compute_features, shard_range
+env = DistEnv(backend="gloo")
+assert env.world_size == 2
+lo, hi = shard_range(6, env.rank, env.world_size)
+def sample_fn(n):
+    return torch.arange(lo, lo + n, dtype=torch.float32).view(n, 1, 1, 1).expand(n, 3, 2, 2).contiguous()
+out = compute_features(env, sample_fn, lambda x: x, 6, 3)
+assert out.shape == (6, 3, 2, 2), out.shape
+assert out[:, 0, 0, 0].tolist() == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0], out[:, 0, 0, 0]
+t = env.max_over_ranks(float(env.rank + 1))
+assert t == 2.0
+env.barrier()
+print("rank", env.rank, "ok")
+'''
+
+
+def test_compute_features_gloo_world2(tmp_path):
+    """N>1 path: contiguous shards, no collective until the final all_gather (gloo on CPU)."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", str(script), ROOT]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("ok") == 2
