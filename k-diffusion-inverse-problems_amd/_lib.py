@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkdip_hip.so")
+LIB_PATH = os.environ.get("KDIP_LIB_PATH", os.path.join(_HERE, "libkdip_hip.so"))   # override: kernel-variant A/B runs
 
 c_float_p = C.POINTER(C.c_float)
 c_int_p = C.POINTER(C.c_int)

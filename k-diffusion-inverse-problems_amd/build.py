@@ -19,9 +19,11 @@ def _newer(src_paths, target):
     return any(os.path.getmtime(p) > t for p in src_paths)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, extra_flags=(), out=None, tag=""):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build" + tag)
+    global OUT
+    out = out or OUT
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "kdip.h"))
@@ -34,7 +36,7 @@ def build(force=False, verbose=True):
 
     def cc(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + list(extra_flags) + ["-x", "hip", "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         return src, r
 
@@ -46,16 +48,22 @@ def build(force=False, verbose=True):
             if verbose:
                 print("compiled", os.path.basename(src))
     objs = [os.path.join(objdir, s.rsplit(".", 1)[0] + ".o") for s in SOURCES]
-    if force or jobs or not os.path.exists(OUT):
-        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs,
+    if force or jobs or not os.path.exists(out):
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs,
                            capture_output=True, text=True)
         if r.returncode != 0:
             sys.stderr.write(r.stdout + r.stderr)
             raise RuntimeError("link failed")
         if verbose:
-            print("linked", OUT)
-    return OUT
+            print("linked", out)
+    return out
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    # python build.py [--force] [--variant TAG -DFLAG ...]  (variants go to libkdip_hip_TAG.so)
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        tag = sys.argv[i + 1]
+        build(force=True, extra_flags=sys.argv[i + 2:], out=os.path.join(HERE, f"libkdip_hip_{tag}.so"), tag="_" + tag)
+    else:
+        build(force="--force" in sys.argv)

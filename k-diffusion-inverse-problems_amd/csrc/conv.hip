@@ -57,11 +57,20 @@ struct ConvParams {
 };
 
 constexpr int KC = 32;            // input channels per B-pipeline stage (one tap of one 32-channel sub-chunk)
+#ifndef KDIP_B_DEPTH
+#define KDIP_B_DEPTH 2
+#endif
+#ifndef KDIP_A_PREFETCH
+#define KDIP_A_PREFETCH 1
+#endif
+#ifndef KDIP_OCC
+#define KDIP_OCC 3
+#endif
 
 // SUBS = 32-channel sub-chunks staged in LDS per barrier (1 for 3x3; up to 4 for 1x1 so a barrier
 // covers 32 MFMAs per wave instead of 8).
 template <typename T, int NTAPS, int WAVES_M, int WAVES_N, int MT, int NT, int SUBS>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(ConvParams p) {
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && MT * NT == 4 && NTAPS == 9) ? KDIP_OCC : 1) void conv_igemm_kernel(ConvParams p) {
   constexpr int NTHREADS = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * MT * 32;
   constexpr int BN = WAVES_N * NT * 32;
@@ -175,32 +184,56 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(ConvP
   };
   uint4 bq0[KS][NT], bq1[KS][NT], bq2[KS][NT];
   load_b(bq0, 0);
-  load_b(bq1, 1);
+  if (KDIP_B_DEPTH == 2) load_b(bq1, 1);
 
+  // A fragments of the next (sub, tap) stage are read from LDS one stage ahead, so the ds_reads
+  // of stage s+1 are in flight under the MFMAs of stage s.
+  auto load_a = [&](uint4 (&dst)[KS][MT], const unsigned char* abuf, int sub, int tap) {
+    const int toff = ((NTAPS == 9) ? ((tap / 3) * HW_ + (tap % 3)) * PIXB : 0) + sub * KC * (int)sizeof(T);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) dst[ks][mt] = *(const uint4*)(abuf + abase[mt] + toff + ks * 32);
+  };
+  uint4 aq0[KS][MT], aq1[KS][MT];
   for (int c = 0; c < nchunks; ++c) {
     const int buf = c & 1;
     if (c + 1 < nchunks) stage_load(c + 1);
     const unsigned char* abuf = smem + buf * abuf_bytes;
+    load_a(aq0, abuf, 0, 0);
 #pragma unroll
     for (int sub = 0; sub < SUBS; ++sub) {
 #pragma unroll
       for (int tap = 0; tap < NTAPS; ++tap) {
-        load_b(bq2, (c * SUBS + sub) * NTAPS + tap + 2);
-        const int toff = ((NTAPS == 9) ? ((tap / 3) * HW_ + (tap % 3)) * PIXB : 0) + sub * KC * (int)sizeof(T);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          uint4 a[MT];
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) a[mt] = *(const uint4*)(abuf + abase[mt] + toff + ks * 32);
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) Mma<T>::run(a[mt], bq0[ks][nt], acc[mt][nt]);
+        load_b(bq2, (c * SUBS + sub) * NTAPS + tap + KDIP_B_DEPTH);
+        {
+          int ntap = tap + 1, nsub = sub;
+          if (ntap == NTAPS) { ntap = 0; nsub = sub + 1; }
+          if (KDIP_A_PREFETCH && nsub < SUBS) load_a(aq1, abuf, nsub, ntap);
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) { bq0[ks][nt] = bq1[ks][nt]; bq1[ks][nt] = bq2[ks][nt]; }
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) Mma<T>::run(aq0[ks][mt], bq0[ks][nt], acc[mt][nt]);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            if (KDIP_B_DEPTH == 2) { bq0[ks][nt] = bq1[ks][nt]; bq1[ks][nt] = bq2[ks][nt]; }
+            else bq0[ks][nt] = bq2[ks][nt];
+          }
+          if (KDIP_A_PREFETCH) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) aq0[ks][mt] = aq1[ks][mt];
+          }
+        }
+        if (!KDIP_A_PREFETCH) {
+          int ntap = tap + 1, nsub = sub;
+          if (ntap == NTAPS) { ntap = 0; nsub = sub + 1; }
+          if (nsub < SUBS) load_a(aq0, abuf, nsub, ntap);
+        }
       }
     }
     if (c + 1 < nchunks) stage_write(buf ^ 1);
