@@ -54,6 +54,15 @@ struct ConvParams {
   float alpha;                    // output scale (applied before bias)
   int cin_real;                   // un-padded input channels (profiling / algorithmic FLOPs only)
   int vec_epilogue;               // LDS-transposed 4-channel-per-lane stores
+  // fused GroupNorm statistics of the OUTPUT tensor (vector epilogue, one image per tile only):
+  //   st_mode 1: sums[b][g] += (sum y, sum y^2)                         -> next GroupNorm forward
+  //   st_mode 2: y is dL/d(GN-apply output); with x = the GN input, z = a*x + b:
+  //              sums[b][g] += (sum a*dz, sum a*dz*xhat), dz = y * silu'(z) | y   -> GroupNorm backward
+  int st_mode, st_silu;
+  double* st_sums;                // [B][32][2], pre-zeroed
+  const void* st_x; long st_ldx;  // mode 2
+  const float* st_coef;           // mode 2: [B][Cout][2] (a, b)
+  const float* st_mr;             // mode 2: [B][32][2] (mean, rstd)
 };
 
 constexpr int KC = 32;            // input channels per B-pipeline stage (one tap of one 32-channel sub-chunk)
@@ -250,6 +259,24 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && MT * NT =
     constexpr int LPR = NT * 8;                        // lanes (4-channel vectors) per pixel row
     constexpr int RPI = 64 / LPR;                      // pixel rows per pass
     unsigned char* creg = smem + wave * 32 * RS;
+    float* sred = (float*)(smem + WAVES_M * WAVES_N * 32 * RS);     // [BN/4][2] block-level stats combine
+    const int vec = lane % LPR;
+    const int nl = nt0 * 32 + vec * 4;                 // this lane's 4 output channels
+    const int cpg = p.Cout >> 5;
+    float s1 = 0.f, s2 = 0.f;
+    float ca[4] = {0, 0, 0, 0}, cb[4] = {0, 0, 0, 0}, gmean = 0.f, grstd = 0.f;
+    if (p.st_mode) {
+      if (tid < BN / 4 * 2) sred[tid] = 0.f;
+      if (p.st_mode == 2 && nl < p.Cout && img0 < p.B) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          ca[e] = p.st_coef[((long)img0 * p.Cout + nl + e) * 2];
+          cb[e] = p.st_coef[((long)img0 * p.Cout + nl + e) * 2 + 1];
+        }
+        gmean = p.st_mr[((long)img0 * 32 + nl / cpg) * 2];
+        grstd = p.st_mr[((long)img0 * 32 + nl / cpg) * 2 + 1];
+      }
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -265,11 +292,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && MT * NT =
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
       for (int it = 0; it < 32 / RPI; ++it) {
-        const int row = it * RPI + lane / LPR, vec = lane % LPR;
+        const int row = it * RPI + lane / LPR;
         const int m = (wm * MT + mt) * 32 + row;
         const int tb = m >> p.lgTHW, rr = m & ((1 << p.lgTHW) - 1);
         const int ty = rr >> p.lgTW, tx = rr & (p.TW - 1);
-        const int gb = img0 + tb, n = nt0 * 32 + vec * 4;
+        const int gb = img0 + tb, n = nl;
         float4 v = *(const float4*)(creg + row * RS + vec * 16);
         if (gb < p.B && n < p.Cout) {
           const long pix = ((long)gb * p.H + (y0 + ty)) * p.W + (x0 + tx);
@@ -283,17 +310,61 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && MT * NT =
               v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
             }
           }
+          float vv[4] = {v.x, v.y, v.z, v.w};
           if (p.out_f32 || sizeof(T) == 4) {
             *(float4*)((float*)p.y + pix * p.ldy + n) = v;
           } else {
             uint2 o;
-            o.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
-            o.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+            bf16_t h0 = f32_to_bf16(v.x), h1 = f32_to_bf16(v.y), h2 = f32_to_bf16(v.z), h3 = f32_to_bf16(v.w);
+            o.x = (uint32_t)h0 | ((uint32_t)h1 << 16);
+            o.y = (uint32_t)h2 | ((uint32_t)h3 << 16);
             *(uint2*)((bf16_t*)p.y + pix * p.ldy + n) = o;
+            vv[0] = bf16_to_f32(h0); vv[1] = bf16_to_f32(h1); vv[2] = bf16_to_f32(h2); vv[3] = bf16_to_f32(h3);   // stats of the stored values
+          }
+          if (p.st_mode == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s1 += vv[e]; s2 += vv[e] * vv[e]; }
+          } else if (p.st_mode == 2) {
+            float xv[4];
+            if (sizeof(T) == 2) {
+              uint2 xr = *(const uint2*)((const bf16_t*)p.st_x + pix * p.st_ldx + n);
+              xv[0] = __uint_as_float(xr.x << 16); xv[1] = __uint_as_float(xr.x & 0xffff0000u);
+              xv[2] = __uint_as_float(xr.y << 16); xv[3] = __uint_as_float(xr.y & 0xffff0000u);
+            } else {
+              float4 xr = *(const float4*)((const float*)p.st_x + pix * p.st_ldx + n);
+              xv[0] = xr.x; xv[1] = xr.y; xv[2] = xr.z; xv[3] = xr.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float z = ca[e] * xv[e] + cb[e];
+              float dz = p.st_silu ? vv[e] * silu_grad_f(z) : vv[e];
+              float adz = ca[e] * dz;
+              s1 += adz;
+              s2 += adz * (xv[e] - gmean) * grstd;
+            }
           }
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    if (p.st_mode) {
+      // rows -> lanes sharing `vec`; then waves -> LDS; then one fp64 atomic pair per 4-channel vector
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+      __syncthreads();                                  // sred zeroed, all waves past their creg use
+      if (lane < LPR) {
+        atomicAdd(&sred[(wn * LPR + lane) * 2], s1);
+        atomicAdd(&sred[(wn * LPR + lane) * 2 + 1], s2);
+      }
+      __syncthreads();
+      if (tid < BN / 4) {
+        const int n = ntb * BN + tid * 4;
+        if (n < p.Cout && img0 < p.B) {
+          double* dst = p.st_sums + ((long)img0 * 32 + n / cpg) * 2;
+          atomicAdd(dst, (double)sred[tid * 2]);
+          atomicAdd(dst + 1, (double)sred[tid * 2 + 1]);
+        }
+      }
     }
     return;
   }
@@ -347,9 +418,11 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
   p.vec_epilogue = (p.Cout % 4 == 0) && (p.ldy % 4 == 0) && (!p.res || p.ldr % 4 == 0) &&
                    ((uintptr_t)p.y % (osz4 ? 16 : 8) == 0) && (!p.res || (uintptr_t)p.res % (sizeof(T) == 2 ? 8 : 16) == 0);
   if (p.vec_epilogue) {
-    size_t cl = (size_t)WAVES_M * WAVES_N * 32 * (NT * 32 * 4 + 16);
+    size_t cl = (size_t)WAVES_M * WAVES_N * 32 * (NT * 32 * 4 + 16) + (size_t)BN / 4 * 2 * sizeof(float);
     if (cl > lds) lds = cl;
   }
+  if (p.st_mode && !(p.vec_epilogue && TB == 1 && p.Cout % 32 == 0 && ((p.Cout >> 5) % 4) == 0))
+    return set_error(KDIP_ERR_UNSUPPORTED, "conv: fused GroupNorm statistics not available for this shape");
   int nblkN = cdiv(p.ntilesN * 32, BN);
   long grid = (long)p.mtiles * nblkN;
   auto kern = conv_igemm_kernel<T, NTAPS, WAVES_M, WAVES_N, MT, NT, SUBS>;
@@ -400,7 +473,7 @@ static int launch_T(ConvParams& p, hipStream_t st) {
 
 int conv_forward(hipStream_t st, DType dt, int ntaps, const void* x, long ldx, int B, int H, int W, int Cin,
                  const void* wp, const float* bias, int Cout, void* y, long ldy, const void* res, long ldr,
-                 int out_f32, float alpha, int cin_real) {
+                 int out_f32, float alpha, int cin_real, const ConvStats* stt) {
   KDIP_REQUIRE(Cin % KC == 0, "conv: Cin=%d must be a multiple of %d (pad the input)", Cin, KC);
   KDIP_REQUIRE(ntaps == 9 || ntaps == 1, "conv: ntaps must be 9 or 1");
   KDIP_REQUIRE((ldx * (dt == DT_BF16 ? 2 : 4)) % 16 == 0, "conv: input channel stride must be 16-byte aligned");
@@ -408,6 +481,11 @@ int conv_forward(hipStream_t st, DType dt, int ntaps, const void* x, long ldx, i
   p.x = x; p.ldx = ldx; p.wp = wp; p.bias = bias; p.res = res; p.ldr = ldr; p.y = y; p.ldy = ldy;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.ntilesN = cdiv(Cout, 32);
   p.out_f32 = out_f32; p.alpha = alpha; p.cin_real = cin_real > 0 ? cin_real : Cin;
+  p.st_mode = 0; p.st_silu = 0; p.st_sums = nullptr; p.st_x = nullptr; p.st_ldx = 0; p.st_coef = nullptr; p.st_mr = nullptr;
+  if (stt && stt->mode) {
+    p.st_mode = stt->mode; p.st_silu = stt->silu; p.st_sums = stt->sums; p.st_x = stt->x; p.st_ldx = stt->ldx;
+    p.st_coef = stt->coef; p.st_mr = stt->mr;
+  }
   if (dt == DT_BF16) return ntaps == 9 ? launch_T<bf16_t, 9>(p, st) : launch_T<bf16_t, 1>(p, st);
   return ntaps == 9 ? launch_T<float, 9>(p, st) : launch_T<float, 1>(p, st);
 }

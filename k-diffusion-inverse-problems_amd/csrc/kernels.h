@@ -5,9 +5,18 @@
 namespace kdip {
 
 // ---- conv.hip ---------------------------------------------------------------------------
+// Optional GroupNorm statistics fused into the conv epilogue (see ConvParams::st_mode).
+struct ConvStats {
+  int mode = 0, silu = 0;
+  double* sums = nullptr;          // [B][32][2], pre-zeroed by the caller
+  const void* x = nullptr; long ldx = 0;
+  const float* coef = nullptr; const float* mr = nullptr;
+};
+// true iff conv_forward can fuse statistics for an output of this shape
+inline bool conv_stats_eligible(int H, int W, int Cout) { return (long)H * W >= 128 && Cout % 128 == 0; }
 int conv_forward(hipStream_t st, DType dt, int ntaps, const void* x, long ldx, int B, int H, int W, int Cin,
                  const void* wp, const float* bias, int Cout, void* y, long ldy, const void* res, long ldr,
-                 int out_f32, float alpha, int cin_real = 0);
+                 int out_f32, float alpha, int cin_real = 0, const ConvStats* stt = nullptr);
 size_t packed_weight_bytes(DType dt, int ntaps, int Cin_pad, int Cout);
 void pack_conv_weight(DType dt, const float* w, int Cout, int Cin, int ntaps, int transpose_flip, int Cin_pad_out,
                       void* out);
@@ -27,7 +36,7 @@ int bgemm(hipStream_t st, DType dt, const BGemm& g);
 
 // ---- norm.hip ---------------------------------------------------------------------------
 // GroupNorm(32) over NHWC [B, HW, C] (ld = channel stride). stats: double [B][32][2] (sum, sumsq), zeroed by callee.
-int gn_stats(hipStream_t st, DType dt, const void* x, long ldx, int B, long HW, int C, double* stats);
+int gn_stats(hipStream_t st, DType dt, const void* x, long ldx, int B, long HW, int C, double* stats, int prezeroed = 0);
 // coef[B][C][2] = (a, b) with y = a*x + b  [then SiLU]; a = rstd*gamma*(1+scale), b = (beta - mean*rstd*gamma)*(1+scale)+shift
 // film: [B][2C] fp32 (scale | shift) or null.  Also writes mr[B][32][2] = (mean, rstd) fp32.
 int gn_coef(hipStream_t st, const double* stats, const float* gamma, const float* beta, const float* film,
@@ -36,7 +45,7 @@ int gn_apply(hipStream_t st, DType dt, const void* x, long ldx, const float* coe
              void* y, long ldy);
 // backward: dy wrt apply output -> dx (+ optional addend), two passes.
 int gn_bwd_stats(hipStream_t st, DType dt, const void* x, long ldx, const void* dy, long lddy, const float* coef,
-                 const float* mr, int B, long HW, int C, int silu, double* sums);
+                 const float* mr, int B, long HW, int C, int silu, double* sums, int prezeroed = 0);
 int gn_bwd_apply(hipStream_t st, DType dt, const void* x, long ldx, const void* dy, long lddy, const float* coef,
                  const float* mr, const double* sums, int B, long HW, int C, int silu, const void* addend, long lda,
                  void* dx, long lddx);

@@ -78,9 +78,9 @@ static long pick_chunk(long HW, int B) {
   return chunk;
 }
 
-int gn_stats(hipStream_t st, DType dt, const void* x, long ldx, int B, long HW, int C, double* stats) {
+int gn_stats(hipStream_t st, DType dt, const void* x, long ldx, int B, long HW, int C, double* stats, int prezeroed) {
   KDIP_REQUIRE(C % 32 == 0, "groupnorm: C=%d not a multiple of 32", C);
-  KDIP_HIP_CHECK(hipMemsetAsync(stats, 0, sizeof(double) * B * 64, st));
+  if (!prezeroed) KDIP_HIP_CHECK(hipMemsetAsync(stats, 0, sizeof(double) * B * 64, st));
   long chunk = pick_chunk(HW, B);
   dim3 grid(cdiv(HW, chunk), B);
   if (dt == DT_BF16) {
@@ -238,8 +238,8 @@ __global__ void gn_bwd_stats_kernel(const T* __restrict__ x, long ldx, const T* 
 }
 
 int gn_bwd_stats(hipStream_t st, DType dt, const void* x, long ldx, const void* dy, long lddy, const float* coef,
-                 const float* mr, int B, long HW, int C, int silu, double* sums) {
-  KDIP_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * B * 64, st));
+                 const float* mr, int B, long HW, int C, int silu, double* sums, int prezeroed) {
+  if (!prezeroed) KDIP_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * B * 64, st));
   long chunk = pick_chunk(HW, B);
   dim3 grid(cdiv(HW, chunk), B);
   if (dt == DT_BF16) {

@@ -67,7 +67,9 @@ struct UNet {
   bool finalized = false;
   std::vector<void*> dev_allocs;
 
-  Arena persist, scratch;
+  Arena persist, scratch, zeros;     // zeros: fp64 statistics accumulators, cleared once per forward / VJP
+  size_t zeros_fwd_end = 0;
+  std::map<const void*, double*> fused_stats;   // tensor -> GroupNorm sums already accumulated by its producer
   int ws_B = 0;
   bool dry = false;
   // state of the last forward (for the VJP)

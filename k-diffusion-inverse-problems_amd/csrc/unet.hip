@@ -63,6 +63,7 @@ UNet::~UNet() {
   for (void* p : dev_allocs) (void)hipFree(p);
   if (persist.base) (void)hipFree(persist.base);
   if (scratch.base) (void)hipFree(scratch.base);
+  if (zeros.base) (void)hipFree(zeros.base);
 }
 
 int UNet::build_plan() {
@@ -225,13 +226,20 @@ struct Ctx {
   UNet* u; hipStream_t st; bool dry; DType dt; size_t es;
 };
 
+double* new_sums(Ctx& c, int B) { return (double*)c.u->zeros.alloc(sizeof(double) * B * 64); }
+
 int gn_forward(Ctx& c, const void* x, long ldx, int B, long HW, const GnW& g, const float* film, int silu, void* y,
                long ldy, float** coef_out, float** mr_out) {
   bool dry = c.dry;
-  double* stats = (double*)c.u->scratch.alloc(sizeof(double) * B * 64);
   float* coef = (float*)c.u->persist.alloc(sizeof(float) * B * g.C * 2);
   float* mr = (float*)c.u->persist.alloc(sizeof(float) * B * 64);
-  RUN(gn_stats(c.st, c.dt, x, ldx, B, HW, g.C, stats));
+  double* stats = nullptr;
+  auto it = c.u->fused_stats.find(x);
+  if (it != c.u->fused_stats.end() && ldx == g.C) stats = it->second;        // accumulated by the producing conv
+  else {
+    stats = new_sums(c, B);
+    RUN(gn_stats(c.st, c.dt, x, ldx, B, HW, g.C, stats, 1));
+  }
   RUN(gn_coef(c.st, stats, g.gamma, g.beta, film, B, HW, g.C, 1e-5f, coef, mr));
   RUN(gn_apply(c.st, c.dt, x, ldx, coef, B, HW, g.C, silu, y, ldy));
   *coef_out = coef; *mr_out = mr;
@@ -239,25 +247,46 @@ int gn_forward(Ctx& c, const void* x, long ldx, int B, long HW, const GnW& g, co
 }
 
 int gn_backward(Ctx& c, const void* x, long ldx, const void* dy, long lddy, const float* coef, const float* mr, int B,
-                long HW, int C, int silu, const void* addend, long lda, void* dx, long lddx) {
+                long HW, int C, int silu, const void* addend, long lda, void* dx, long lddx, double* fused_sums = nullptr) {
   bool dry = c.dry;
-  double* sums = (double*)c.u->scratch.alloc(sizeof(double) * B * 64);
-  RUN(gn_bwd_stats(c.st, c.dt, x, ldx, dy, lddy, coef, mr, B, HW, C, silu, sums));
+  double* sums = fused_sums;
+  if (!sums) {
+    sums = new_sums(c, B);
+    RUN(gn_bwd_stats(c.st, c.dt, x, ldx, dy, lddy, coef, mr, B, HW, C, silu, sums, 1));
+  }
   RUN(gn_bwd_apply(c.st, c.dt, x, ldx, dy, lddy, coef, mr, sums, B, HW, C, silu, addend, lda, dx, lddx));
   return KDIP_OK;
 }
 
 int conv_f(Ctx& c, const ConvW& w, const void* x, long ldx, int B, int H, int W, void* y, long ldy, const void* res,
-           long ldr, int out_f32) {
+           long ldr, int out_f32, bool fuse_out_stats = false) {
   bool dry = c.dry;
-  RUN(conv_forward(c.st, c.dt, w.ntaps, x, ldx, B, H, W, w.cin_pad, w.wf, w.bias, w.cout, y, ldy, res, ldr, out_f32, 1.f, w.cin));
+  ConvStats stt;
+  if (fuse_out_stats && !out_f32 && ldy == w.cout && conv_stats_eligible(H, W, w.cout)) {
+    stt.mode = 1;
+    stt.sums = new_sums(c, B);
+    c.u->fused_stats[y] = stt.sums;
+  }
+  RUN(conv_forward(c.st, c.dt, w.ntaps, x, ldx, B, H, W, w.cin_pad, w.wf, w.bias, w.cout, y, ldy, res, ldr, out_f32, 1.f, w.cin,
+                   stt.mode ? &stt : nullptr));
   return KDIP_OK;
 }
 // input-gradient: x here is dL/d(out) with >= cin_pad_b channels available (zero padded when cout % 32 != 0)
+// gn_*: when given, the GroupNorm-backward sums of the produced gradient (w.r.t. the GN whose input is
+// gn_x) are accumulated in the epilogue; *sums_out receives the buffer (or nullptr if not eligible).
 int conv_b(Ctx& c, const ConvW& w, const void* g, long ldg, int B, int H, int W, void* y, long ldy, const void* res,
-           long ldr, int out_f32) {
+           long ldr, int out_f32, const void* gn_x = nullptr, long gn_ldx = 0, const float* gn_coef = nullptr,
+           const float* gn_mr = nullptr, int gn_silu = 0, double** sums_out = nullptr) {
   bool dry = c.dry;
-  RUN(conv_forward(c.st, c.dt, w.ntaps, g, ldg, B, H, W, w.cin_pad_b, w.wb, nullptr, w.cin, y, ldy, res, ldr, out_f32, 1.f, w.cout));
+  ConvStats stt;
+  if (sums_out) *sums_out = nullptr;
+  if (gn_x && sums_out && !out_f32 && ldy == w.cin && conv_stats_eligible(H, W, w.cin)) {
+    stt.mode = 2; stt.silu = gn_silu; stt.x = gn_x; stt.ldx = gn_ldx; stt.coef = gn_coef; stt.mr = gn_mr;
+    stt.sums = new_sums(c, B);
+    *sums_out = stt.sums;
+  }
+  RUN(conv_forward(c.st, c.dt, w.ntaps, g, ldg, B, H, W, w.cin_pad_b, w.wb, nullptr, w.cin, y, ldy, res, ldr, out_f32, 1.f, w.cout,
+                   stt.mode ? &stt : nullptr));
   return KDIP_OK;
 }
 }  // namespace
@@ -325,7 +354,7 @@ static int res_forward(Ctx& c, Layer& L, const void* x, long ldx, int B, int& H,
   const long HWo = (long)Ho * Wo;
   void* h2 = u->persist.alloc(es * B * HWo * L.cout);
   L.sv.h2 = h2;
-  CK(conv_f(c, L.c1, cin_ptr, L.cin, B, Ho, Wo, h2, L.cout, nullptr, 0, 0));
+  CK(conv_f(c, L.c1, cin_ptr, L.cin, B, Ho, Wo, h2, L.cout, nullptr, 0, 0, true));
   float* film = (float*)u->scratch.alloc(sizeof(float) * B * 2 * L.cout);
   RUN(linear_f32(c.st, emb, L.emb, B, 1, film));
   void* h3 = u->scratch.alloc(es * B * HWo * L.cout);
@@ -337,7 +366,7 @@ static int res_forward(Ctx& c, Layer& L, const void* x, long ldx, int B, int& H,
     S = sk; ldS = L.cout;
   }
   void* o = u->persist.alloc(es * B * HWo * L.cout);
-  CK(conv_f(c, L.c2, h3, L.cout, B, Ho, Wo, o, L.cout, S, ldS, 0));
+  CK(conv_f(c, L.c2, h3, L.cout, B, Ho, Wo, o, L.cout, S, ldS, 0, true));
   *outp = o; H = Ho; W = Wo;
   return KDIP_OK;
 }
@@ -381,7 +410,7 @@ static int attn_forward(Ctx& c, Layer& L, const void* x, long ldx, int B, int H,
   RUN(softmax_rows(c.st, c.dt, S, (long)B * heads * T, T, P));
   RUN(bgemm(c.st, c.dt, pv));
   void* o = u->persist.alloc(es * (size_t)B * T * C);
-  CK(conv_f(c, L.proj, a, C, B, H, W, o, C, x, ldx, 0));
+  CK(conv_f(c, L.proj, a, C, B, H, W, o, C, x, ldx, 0, true));
   *outp = o;
   return KDIP_OK;
 }
@@ -390,7 +419,8 @@ int UNet::forward_impl(hipStream_t st, const float* x_nchw, const float* t, int 
                        float* cov_nchw, float* feat_nchw) {
   Ctx c{this, st, dry, dt, esize()};
   const size_t es = esize();
-  persist.reset(); scratch.reset();
+  persist.reset(); scratch.reset(); zeros.reset(); fused_stats.clear();
+  if (!dry && zeros.cap) KDIP_HIP_CHECK(hipMemsetAsync(zeros.base, 0, zeros.cap, st));
   int H = cfg.image_size, W = cfg.image_size;
   const int mc = cfg.model_channels, ted = mc * 4;
   // timestep embedding MLP (fp32)
@@ -413,7 +443,7 @@ int UNet::forward_impl(hipStream_t st, const float* x_nchw, const float* t, int 
         scratch.reset();
         o = persist.alloc(es * (size_t)B * H * W * L.cout);
         L.sv.B = B; L.sv.H = H; L.sv.W = W;
-        CK(conv_f(c, L.conv, xin, 32, B, H, W, o, L.cout, nullptr, 0, 0));
+        CK(conv_f(c, L.conv, xin, 32, B, H, W, o, L.cout, nullptr, 0, 0, true));
       } else if (L.kind == 1) {
         CK(res_forward(c, L, h, ldh, B, H, W, emb, &o));
       } else {
@@ -456,6 +486,7 @@ int UNet::forward_impl(hipStream_t st, const float* x_nchw, const float* t, int 
     RUN(nhwc_to_nchw_f32(st, c32, 32, B, 6, H, W, cov_nchw));
   }
   if (feat_nchw) RUN(nhwc_T_to_nchw_f32(st, dt, h, ldh, B, final_ch, H, W, feat_nchw));
+  zeros_fwd_end = (zeros.off + 255) & ~(size_t)255;
   return KDIP_OK;
 }
 
@@ -472,12 +503,17 @@ static int res_backward(Ctx& c, Layer& L, const void* G, long ldG, void** gxp) {
   const long HW = (long)H * W, HWo = (long)Ho * Wo;
   // conv2 dgrad -> grad wrt h3 ; GN2/FiLM/SiLU backward -> grad wrt h2
   void* g3 = u->scratch.alloc(es * B * HWo * L.cout);
-  CK(conv_b(c, L.c2, G, ldG, B, Ho, Wo, g3, L.cout, nullptr, 0, 0));
+  double* sums2 = nullptr;     // GN2-backward sums accumulated by the dgrad epilogue when the shape allows
+  CK(conv_b(c, L.c2, G, ldG, B, Ho, Wo, g3, L.cout, nullptr, 0, 0, L.sv.h2, L.cout, L.sv.coef2, L.sv.mr2, 1, &sums2));
   void* gh2 = u->scratch.alloc(es * B * HWo * L.cout);
-  CK(gn_backward(c, L.sv.h2, L.cout, g3, L.cout, L.sv.coef2, L.sv.mr2, B, HWo, L.cout, 1, nullptr, 0, gh2, L.cout));
+  CK(gn_backward(c, L.sv.h2, L.cout, g3, L.cout, L.sv.coef2, L.sv.mr2, B, HWo, L.cout, 1, nullptr, 0, gh2, L.cout, sums2));
   // conv1 dgrad -> grad wrt (resampled) h1
   void* g1p = u->scratch.alloc(es * B * HWo * L.cin);
-  CK(conv_b(c, L.c1, gh2, L.cout, B, Ho, Wo, g1p, L.cin, nullptr, 0, 0));
+  double* sums1 = nullptr;
+  if (L.mode == 0)
+    CK(conv_b(c, L.c1, gh2, L.cout, B, Ho, Wo, g1p, L.cin, nullptr, 0, 0, L.sv.x, L.sv.ldx, L.sv.coef1, L.sv.mr1, 1, &sums1));
+  else
+    CK(conv_b(c, L.c1, gh2, L.cout, B, Ho, Wo, g1p, L.cin, nullptr, 0, 0));
   // skip path: grad wrt (resampled) x
   const void* gS = G; long ldgS = ldG;
   if (L.has_skip) {
@@ -500,7 +536,7 @@ static int res_backward(Ctx& c, Layer& L, const void* G, long ldG, void** gxp) {
     g1 = a; gxs = b; ldgxs = L.cin;
   }
   void* gx = u->persist.alloc(es * B * HW * L.cin);
-  CK(gn_backward(c, L.sv.x, L.sv.ldx, g1, L.cin, L.sv.coef1, L.sv.mr1, B, HW, L.cin, 1, gxs, ldgxs, gx, L.cin));
+  CK(gn_backward(c, L.sv.x, L.sv.ldx, g1, L.cin, L.sv.coef1, L.sv.mr1, B, HW, L.cin, 1, gxs, ldgxs, gx, L.cin, sums1));
   *gxp = gx;
   return KDIP_OK;
 }
@@ -545,9 +581,10 @@ static int attn_backward(Ctx& c, Layer& L, const void* G, long ldG, void** gxp) 
   g.M = T; g.N = hc; g.K = T; g.nb1 = B; g.nb2 = heads; g.alpha = alpha; g.c_f32 = 0;
   RUN(bgemm(c.st, c.dt, g));
   void* gn_in = u->scratch.alloc(es * (size_t)B * T * C);
-  CK(conv_b(c, L.qkv, dqkv, 3 * C, B, H, W, gn_in, C, nullptr, 0, 0));
+  double* sumsn = nullptr;
+  CK(conv_b(c, L.qkv, dqkv, 3 * C, B, H, W, gn_in, C, nullptr, 0, 0, L.sv.x, L.sv.ldx, L.sv.coef1, L.sv.mr1, 0, &sumsn));
   void* gx = u->persist.alloc(es * (size_t)B * T * C);
-  CK(gn_backward(c, L.sv.x, L.sv.ldx, gn_in, C, L.sv.coef1, L.sv.mr1, B, T, C, 0, G, ldG, gx, C));
+  CK(gn_backward(c, L.sv.x, L.sv.ldx, gn_in, C, L.sv.coef1, L.sv.mr1, B, T, C, 0, G, ldG, gx, C, sumsn));
   *gxp = gx;
   return KDIP_OK;
 }
@@ -559,17 +596,17 @@ int UNet::vjp_impl(hipStream_t st, const float* cot_nchw, float* gx_nchw) {
   const int H0 = cfg.image_size, W0 = cfg.image_size;
   const long HW0 = (long)H0 * W0;
   scratch.reset();
+  zeros.off = zeros_fwd_end;
+  if (!dry && zeros.cap > zeros_fwd_end)
+    KDIP_HIP_CHECK(hipMemsetAsync(zeros.base + zeros_fwd_end, 0, zeros.cap - zeros_fwd_end, st));
   // cotangent NCHW fp32 [B,out_ch,H,W] -> NHWC T padded to 32 channels
   void* cot = persist.alloc(es * B * HW0 * 32);
   RUN(nchw_to_nhwc(st, dt, cot_nchw, B, cfg.out_channels, H0, W0, 1.f, cot, 32, 32));
   void* ghn = scratch.alloc(es * B * HW0 * final_ch);
-  CK(conv_b(c, out_conv, cot, 32, B, H0, W0, ghn, final_ch, nullptr, 0, 0));
+  double* sumsh = nullptr;
+  CK(conv_b(c, out_conv, cot, 32, B, H0, W0, ghn, final_ch, nullptr, 0, 0, final_h, final_ch, out_coef, out_mr, 1, &sumsh));
   void* G = persist.alloc(es * B * HW0 * final_ch);
-  {
-    const Layer& lastL = out.back().back();
-    (void)lastL;
-    CK(gn_backward(c, final_h, final_ch, ghn, final_ch, out_coef, out_mr, B, HW0, final_ch, 1, nullptr, 0, G, final_ch));
-  }
+  CK(gn_backward(c, final_h, final_ch, ghn, final_ch, out_coef, out_mr, B, HW0, final_ch, 1, nullptr, 0, G, final_ch, sumsh));
   const void* g = G; long ldg = final_ch;
   auto back_layers = [&](std::vector<Layer>& ls) -> int {
     for (int i = (int)ls.size() - 1; i >= 0; --i) {
@@ -629,7 +666,8 @@ int UNet::ensure_workspace(int B) {
   // dry run of forward + vjp to measure both arenas
   if (persist.base) { KDIP_HIP_CHECK(hipFree(persist.base)); persist.base = nullptr; }
   if (scratch.base) { KDIP_HIP_CHECK(hipFree(scratch.base)); scratch.base = nullptr; }
-  persist = Arena(); scratch = Arena();
+  if (zeros.base) { KDIP_HIP_CHECK(hipFree(zeros.base)); zeros.base = nullptr; }
+  persist = Arena(); scratch = Arena(); zeros = Arena();
   dry = true;
   float dummy = 0;
   int rc = forward_impl(nullptr, &dummy, &dummy, B, 1.f, &dummy, has_cov ? &dummy : nullptr, &dummy);
@@ -639,8 +677,11 @@ int UNet::ensure_workspace(int B) {
   have_stash = false;
   if (rc) return rc;
   (void)fwd_off;
-  size_t pp = persist.peak + (1 << 20), sp = scratch.peak + (1 << 20);
-  persist = Arena(); scratch = Arena();
+  size_t pp = persist.peak + (1 << 20), sp = scratch.peak + (1 << 20), zp = zeros.peak + 4096;
+  persist = Arena(); scratch = Arena(); zeros = Arena();
+  if (hipMalloc((void**)&zeros.base, zp) != hipSuccess)
+    return set_error(KDIP_ERR_NOMEM, "workspace: hipMalloc(%zu) failed", zp);
+  zeros.cap = zp;
   if (hipMalloc((void**)&persist.base, pp) != hipSuccess)
     return set_error(KDIP_ERR_NOMEM, "workspace: hipMalloc(%zu) failed", pp);
   if (hipMalloc((void**)&scratch.base, sp) != hipSuccess)

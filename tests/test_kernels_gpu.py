@@ -142,9 +142,9 @@ def test_unet_tiny_golden(gold, dtype, tol):
     assert rel_err(cov.cpu(), cov_ref) < tol
     vj = m.vjp(torch.from_numpy(g["cot"]).cuda())
     assert rel_err(vj.cpu(), torch.from_numpy(g["vjp"])) < tol
-    # the stash survives: a second VJP gives the same answer
+    # the stash survives: a second VJP gives the same answer (up to fp64-atomic summation order)
     vj2 = m.vjp(torch.from_numpy(g["cot"]).cuda())
-    assert torch.equal(vj, vj2)
+    assert rel_err(vj2, vj) < 1e-5
 
 
 def test_unet_missing_weight_fails_loudly():
