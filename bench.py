@@ -190,28 +190,38 @@ def main():
         n = lib.kdip_profile_num_classes()
         ms = (C.c_double * n)(); fl = (C.c_double * n)(); by = (C.c_double * n)(); la = (C.c_long * n)()
         L.check(lib.kdip_profile_report(ms, fl, by, la))
-        if os.environ.get("KDIP_PROFILE_DUMP"):
-            L.check(lib.kdip_profile_dump(os.environ["KDIP_PROFILE_DUMP"].encode()))
-        L.check(lib.kdip_profile_enable(0))
-        k = max(range(n), key=lambda j: ms[j])
-        tflops = fl[k] / (ms[k] * 1e-3) / 1e12 if ms[k] > 0 else 0.0
+        # dominant kernel = the (kernel class, layer shape) with the largest total time in the profiled pass
+        import csv, tempfile, collections
+        dump = os.environ.get("KDIP_PROFILE_DUMP") or os.path.join(tempfile.gettempdir(), f"kdip_conv_dump_{os.getpid()}.csv")
+        L.check(lib.kdip_profile_dump(dump.encode()))
+        grp = collections.defaultdict(lambda: [0, 0.0, 0.0])
+        for r in csv.DictReader(open(dump)):
+            key = (r["class"], r["d0"], r["d1"], r["d2"], r["d3"])
+            grp[key][0] += 1; grp[key][1] += float(r["us"]); grp[key][2] += float(r["gflop"])
+        key, (cnt, us, gf) = max(grp.items(), key=lambda kv: kv[1][1])
+        tflops = gf / us * 1e3 if us > 0 else 0.0          # GFLOP / us = PFLOP/s
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_conv3x3_latest.json")   # filled from rocprofv3 --pmc passes, if committed
+        pmc = os.path.join(ROOT, "profiles", "pmc_conv3x3_latest.json")   # rocprofv3 --pmc passes on the same kernel + shape
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                pj = json.load(open(pmc))
+                if pj.get("shape_key") == "|".join(key):
+                    traffic = pj.get("hbm_bytes_per_launch_bf16_out")
             except Exception:
                 traffic = None
+        k = max(range(n), key=lambda j: ms[j])
         out["roofline"] = {
-            "kernel": lib.kdip_profile_class_name(k).decode() + " (bf16, v_mfma_f32_32x32x16_bf16)",
+            "kernel": f"{key[0]} (conv_igemm_kernel<bf16,9,2,2,2,2,1>, v_mfma_f32_32x32x16_bf16), layer B={key[1]} {key[3]}->{key[4]} ch @ {key[2]}x{key[2]}",
             "bound": "mfma", "achieved": round(tflops, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tflops / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-            "launches": int(la[k]), "avg_launch_us": round(ms[k] * 1e3 / max(la[k], 1), 2),
-            "algorithmic_gflop_per_launch": round(fl[k] / max(la[k], 1) / 1e9, 3),
-            "share_of_profiled_conv_time": round(ms[k] / max(sum(ms), 1e-9), 3),
+            "launches": cnt, "avg_launch_us": round(us / cnt, 2), "algorithmic_gflop_per_launch": round(gf / cnt, 3),
+            "share_of_profiled_conv_time": round(us / max(sum(v[1] for v in grp.values()), 1e-9), 3),
+            "class_aggregate": {"kernel_class": lib.kdip_profile_class_name(k).decode(), "tflops": round(fl[k] / max(ms[k], 1e-9) / 1e9, 2),
+                                "launches": int(la[k]), "avg_launch_us": round(ms[k] * 1e3 / max(la[k], 1), 2)},
             "all_conv_classes": {lib.kdip_profile_class_name(j).decode(): {"ms": round(ms[j], 3), "tflops": round(fl[j] / max(ms[j], 1e-9) / 1e9, 2), "launches": int(la[j])}
                                  for j in range(n) if la[j] > 0},
         }
+        L.check(lib.kdip_profile_enable(0))
 
     # ---- CPU baseline (rank 0, single-GPU runs only; bounded sample)
     if not args.no_cpu_baseline and env.is_main_process and env.world_size == 1:

@@ -72,6 +72,15 @@ constexpr int KC = 32;            // input channels per B-pipeline stage (one ta
 #ifndef KDIP_A_PREFETCH
 #define KDIP_A_PREFETCH 1
 #endif
+#ifndef KDIP_TW
+#define KDIP_TW 16
+#endif
+#ifndef KDIP_BIG
+#define KDIP_BIG 0
+#endif
+#ifndef KDIP_WLAYOUT
+#define KDIP_WLAYOUT 0
+#endif
 #ifndef KDIP_OCC
 #define KDIP_OCC 3
 #endif
@@ -79,7 +88,7 @@ constexpr int KC = 32;            // input channels per B-pipeline stage (one ta
 // SUBS = 32-channel sub-chunks staged in LDS per barrier (1 for 3x3; up to 4 for 1x1 so a barrier
 // covers 32 MFMAs per wave instead of 8).
 template <typename T, int NTAPS, int WAVES_M, int WAVES_N, int MT, int NT, int SUBS>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && MT * NT == 4 && NTAPS == 9) ? KDIP_OCC : 1) void conv_igemm_kernel(ConvParams p) {
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 9) ? (MT * NT == 4 ? KDIP_OCC : (MT * NT == 8 ? 2 : 1)) : 1) void conv_igemm_kernel(ConvParams p) {
   constexpr int NTHREADS = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * MT * 32;
   constexpr int BN = WAVES_N * NT * 32;
@@ -93,7 +102,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && MT * NT =
   constexpr int MAXV = (MAXPIX * VPP + NTHREADS - 1) / NTHREADS;   // staged 16-byte vectors per thread
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // wave index made provably wave-uniform: everything derived from it (weight-fragment base
+  // pointers, LDS regions) then lives in SGPRs and the B loads use the saddr + lane-offset form.
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
   // ---- XCD-aware bijective remap: XCD k (= bid % 8) gets a contiguous logical range
@@ -142,14 +154,21 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && MT * NT =
     int ty = rr >> p.lgTW, tx = rr & (p.TW - 1);
     abase[mt] = ((tb * HH_ + ty) * HW_ + tx) * PIXB + (lane >> 5) * 16;
   }
-  // ---- B fragment pointers
+  // ---- B fragment pointers (uniform base per n-tile + lane)
   const int nt0 = ntb * (BN / 32) + wn * NT;           // first n-tile of this wave
   const uint4* wp = (const uint4*)p.wp;
   const long kstepsTotal = (long)(p.Cin / KSTEP);
-  auto bptr = [&](int tap, long kstep, int nt) -> const uint4* {
+  const long kStride = (long)p.ntilesN * 64;           // uint4 per k-step
+  const long tapStride = kstepsTotal * kStride;        // uint4 per tap
+  const uint4* wbase[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
     int ntile = nt0 + nt;
     ntile = ntile < p.ntilesN ? ntile : p.ntilesN - 1;  // clamp (results discarded)
-    return wp + (((long)tap * kstepsTotal + kstep) * p.ntilesN + ntile) * 64 + lane;
+    wbase[nt] = wp + (long)ntile * 64;
+  }
+  auto bptr = [&](int tap, long kstep, int nt) -> const uint4* {
+    return wbase[nt] + (tap * tapStride + kstep * kStride) + lane;
   };
 
   f32x16 acc[MT][NT];
@@ -207,7 +226,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && MT * NT =
   uint4 aq0[KS][MT], aq1[KS][MT];
   for (int c = 0; c < nchunks; ++c) {
     const int buf = c & 1;
-    if (c + 1 < nchunks) stage_load(c + 1);
+    // The loop-carried `s_waitcnt vmcnt(0)` hipcc places before the first MFMA of an iteration would
+    // also wait for the (HBM-latency) A-stage loads of the next chunk if they were issued first:
+    // issue them after the first stage's MFMAs instead (3x3), so only the old B loads are waited for.
+    if (NTAPS * SUBS == 1 && c + 1 < nchunks) stage_load(c + 1);
     const unsigned char* abuf = smem + buf * abuf_bytes;
     load_a(aq0, abuf, 0, 0);
 #pragma unroll
@@ -226,6 +248,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && MT * NT =
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) Mma<T>::run(aq0[ks][mt], bq0[ks][nt], acc[mt][nt]);
+        if (NTAPS * SUBS > 1 && sub == 0 && tap == 0 && c + 1 < nchunks) stage_load(c + 1);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -398,7 +421,10 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
   constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32;
   constexpr int PIXB = KC * SUBS * (int)sizeof(T) + 16;
   constexpr int HALO = (NTAPS == 9) ? 1 : 0;
-  int TW = p.W < 16 ? p.W : 16;
+  // 32-pixel-wide patches: an MFMA m-tile (32 rows) is one patch row, so the 16-lane groups of
+  // ds_read_b128 see 16 consecutive pixels (5-slot stride -> conflict free); 16-wide patches put two
+  // patch rows in one m-tile and collide on 2 of 16 slots.
+  int TW = p.W < KDIP_TW ? p.W : KDIP_TW;
   int TH = p.H < BM / TW ? p.H : BM / TW;
   int TB = BM / (TH * TW);
   auto ispow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
@@ -462,6 +488,11 @@ static int launch_T(ConvParams& p, hipStream_t st) {
   // Small-spatial layers (8x8 ... 32x32) are weight-streaming / latency bound: more, narrower
   // blocks spread the weight reads over more CUs.
   const long mt = cdiv((long)p.B * p.H * p.W, 128);
+  // 256x128 block (wave tile 128x64: every B fragment feeds 4 MFMAs, every A fragment 2 -> half the
+  // L1 operand traffic per MFMA of the 64x64 wave tile) when there is enough work for >= 2 blocks/CU
+  if (KDIP_BIG && sizeof(T) == 2 && NTAPS == 9 && npad >= 128 && (mt / 2) * cdiv(npad, 128) >= 512 && p.H * p.W >= 256)
+    return launch_cfg<T, NTAPS, 2, 2, 4, 2>(p, st);
+  if (KDIP_WLAYOUT && sizeof(T) == 2 && NTAPS == 9 && npad >= 128 && mt * cdiv(npad, 128) >= 512) return launch_cfg<T, NTAPS, 1, 4, 4, 1>(p, st);
   if (npad >= 128 && mt * cdiv(npad, 128) >= 512) return launch_cfg<T, NTAPS, 2, 2, 2, 2>(p, st);
   if (npad >= 64 && mt * cdiv(npad, 64) >= 512) return launch_cfg<T, NTAPS, 2, 2, 2, 1>(p, st);
   if (npad >= 128 && mt * cdiv(npad, 32) < 256) return launch_cfg<T, NTAPS, 4, 1, 1, 1>(p, st);
