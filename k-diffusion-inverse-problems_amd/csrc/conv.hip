@@ -49,6 +49,7 @@ struct ConvParams {
   int ntilesN;                    // Cout padded / 32
   int TH, TW, TB;                 // patch geometry (powers of two), TH*TW*TB == BM
   int lgTW, lgTHW;
+  int magicRow, magicPatch;       // ceil(2^20 / (TW+2*halo)), ceil(2^20 / ((TH+2*halo)*(TW+2*halo)))
   int tilesX, tilesY, mtiles;     // per-image tiles, total M tiles
   int out_f32;                    // store fp32 regardless of T
   float alpha;                    // output scale (applied before bias)
@@ -77,6 +78,9 @@ constexpr int KC = 32;            // input channels per B-pipeline stage (one ta
 #endif
 #ifndef KDIP_BIG
 #define KDIP_BIG 0
+#endif
+#ifndef KDIP_SUBS3
+#define KDIP_SUBS3 1
 #endif
 #ifndef KDIP_WLAYOUT
 #define KDIP_WLAYOUT 0
@@ -137,8 +141,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
     goff[i] = -1;
     loff[i] = -1;
     if (pix < npix) {
-      int tb = pix / (HH_ * HW_), rr = pix % (HH_ * HW_);
-      int hy = rr / HW_, hx = rr % HW_;
+      // magic reciprocals (exact for the patch sizes used): avoids ~40-instruction integer divisions
+      int tb = (pix * p.magicPatch) >> 20, rr = pix - tb * (HH_ * HW_);
+      int hy = (rr * p.magicRow) >> 20, hx = rr - hy * HW_;
       int gy = y0 + hy - HALO, gx = x0 + hx - HALO, gb = img0 + tb;
       loff[i] = pix * PIXB + sub * 16;
       if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && gb < p.B)
@@ -434,6 +439,11 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
     return set_error(KDIP_ERR_UNSUPPORTED, "conv: bad multi-image tile");
   p.TH = TH; p.TW = TW; p.TB = TB;
   p.lgTW = __builtin_ctz(TW); p.lgTHW = __builtin_ctz(TH * TW);
+  {
+    const int hw = TW + 2 * HALO, hp = (TH + 2 * HALO) * hw;
+    p.magicRow = ((1 << 20) + hw - 1) / hw;        // exact for x < 1100, d <= 400 (checked on the host)
+    p.magicPatch = ((1 << 20) + hp - 1) / hp;
+  }
   p.tilesX = p.W / TW; p.tilesY = p.H / TH;
   p.mtiles = cdiv(p.B, TB) * p.tilesX * p.tilesY;
   int npix = TB * (TH + 2 * HALO) * (TW + 2 * HALO);
@@ -478,6 +488,10 @@ static int launch_cfg(ConvParams& p, hipStream_t st) {
     if (sizeof(T) == 2 && p.Cin % 128 == 0) return launch_cfg2<T, NTAPS, WAVES_M, WAVES_N, MT, NT, (NTAPS == 1 ? 4 : 1)>(p, st);
     if (sizeof(T) == 2 && p.Cin % 64 == 0) return launch_cfg2<T, NTAPS, WAVES_M, WAVES_N, MT, NT, (NTAPS == 1 ? 2 : 1)>(p, st);
   }
+#if KDIP_SUBS3 > 1
+  if (NTAPS == 9 && sizeof(T) == 2 && MT * NT == 4 && p.Cin % (32 * KDIP_SUBS3) == 0)
+    return launch_cfg2<T, NTAPS, WAVES_M, WAVES_N, MT, NT, (NTAPS == 9 ? KDIP_SUBS3 : 1)>(p, st);
+#endif
   return launch_cfg2<T, NTAPS, WAVES_M, WAVES_N, MT, NT, 1>(p, st);
 }
 
