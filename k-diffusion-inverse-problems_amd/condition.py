@@ -131,17 +131,8 @@ class ConditionDenoiser(nn.Module):
     def _dps_guidance_impl(self, x, sigma):
         assert self.zeta is not None, "zeta must be specified for DPS guidance"
         x0_mean = self.uncond_pred(x, sigma)[0]
-        ax = self.operator.forward(x0_mean, noiseless=True)
-        diff = torch.empty_like(ax)
-        L.check(self.lib.kdip_axpby(L.stream(), L.ptr(self.y.contiguous()), 1.0, L.ptr(ax), -1.0, ax.numel(), L.ptr(diff)))
-        atr = self.operator.forward_adjoint(diff).contiguous()
-        B = x0_mean.shape[0]
-        ghat = torch.empty_like(atr)
-        nrm = torch.empty(B, device=x.device)
-        tmp = torch.empty(B, device=x.device, dtype=torch.float64)
         # -zeta * grad ||y - A x0||_2  =  (dx0/dx)^T [ zeta * A^T r / ||r|| ], norm per sample
-        L.check(self.lib.kdip_dps_normalize(L.stream(), L.ptr(atr), atr[0].numel(), L.ptr(diff), diff[0].numel(),
-                                            float(self.zeta), B, L.ptr(ghat), L.ptr(nrm), L.ptr(tmp)))
+        ghat = self._dps_cotangent(x0_mean)
         likelihood_score = self._vjp_x0(ghat)
         return self._combine(x0_mean, likelihood_score, sigma_host(sigma) ** 2)
 
@@ -161,10 +152,47 @@ class ConditionDenoiser(nn.Module):
         mat = self.mat_solver(self.operator, self.y, x0_mean, x0_var)
         return self._combine(x0_mean, mat, float(x0_var))
 
+    def _axpby(self, x, a, y, b):
+        out = torch.empty_like(x)
+        L.check(self.lib.kdip_axpby(L.stream(), L.ptr(x.contiguous()), float(a), L.ptr(y.contiguous()) if y is not None else None,
+                                    float(b), x.numel(), L.ptr(out)))
+        return out
+
+    def _dps_cotangent(self, x0_mean):
+        """zeta * A^T r / ||r||_2 with r = y - A x0 (per-sample norm): the cotangent whose VJP is
+        -zeta * grad_x ||y - A x0(x)||."""
+        ax = self.operator.forward(x0_mean, noiseless=True)
+        diff = self._axpby(self.y, 1.0, ax, -1.0)
+        atr = self.operator.forward_adjoint(diff).contiguous()
+        B = x0_mean.shape[0]
+        ghat = torch.empty_like(atr)
+        nrm = torch.empty(B, device=x0_mean.device)
+        tmp = torch.empty(B, device=x0_mean.device, dtype=torch.float64)
+        L.check(self.lib.kdip_dps_normalize(L.stream(), L.ptr(atr), atr[0].numel(), L.ptr(diff), diff[0].numel(),
+                                            float(self.zeta), B, L.ptr(ghat), L.ptr(nrm), L.ptr(tmp)))
+        return ghat
+
     def _stsl_guidance_impl(self, x, sigma):
+        """STSL (condition.py:185-208): first-order DPS term + Hutchinson estimate of the second-order
+        term.  With c = eta * sigma^2 / (n * numel):
+            score = J(x)^T [zeta A^T r/||r|| + c sum_k eps_k] - c sum_k J(x + eps_k)^T eps_k
+        i.e. one VJP at x and one forward + VJP per probe (no autograd graph is kept)."""
         assert self.zeta is not None and self.eta is not None and self.num_hutchinson_samples is not None, \
             "zeta, eta, and num_hutchinson_samples must be specified for STSL guidance"
-        raise NotImplementedError("STSL guidance is scheduled after the hot path (SURVEY.md section 8f-4)")
+        n = self.num_hutchinson_samples
+        s2 = sigma_host(sigma) ** 2
+        x0_mean = self.uncond_pred(x, sigma)[0]
+        cot = self._dps_cotangent(x0_mean)
+        probes = getattr(self, "stsl_eps", None)
+        eps_list = [torch.randn_like(x) for _ in range(n)] if probes is None else [e.to(x.device) for e in probes]
+        c = float(self.eta) * s2 / (n * x[0].numel())
+        for eps in eps_list:
+            cot = self._axpby(cot, 1.0, eps, c)
+        score = self._vjp_x0(cot)
+        for eps in eps_list:
+            self.uncond_pred(self._axpby(x, 1.0, eps, 1.0), sigma)
+            score = self._axpby(score, 1.0, self._vjp_x0(eps), -c)
+        return self._combine(x0_mean, score, s2)
 
 
 class ConditionOpenAIDenoiser(ConditionDenoiser):
@@ -194,8 +222,6 @@ class ConditionOpenAIDenoiser(ConditionDenoiser):
         ct = self.x0_cov_type
         if ct not in ('convert', 'analytic', 'pgdm', 'dps', 'diffpir', 'tmpd'):
             raise ValueError('Invalid posterior covariance type.')
-        if ct == 'tmpd':
-            raise NotImplementedError("'tmpd' covariance is scheduled after the hot path (SURVEY.md section 8f-4)")
         low = float(s) < self.mle_sigma_thres
         want_var = ct == 'convert' and low
         tables = (c_in, D.f32('sqrt_recip_alphas_cumprod', t), D.f32('sqrt_recipm1_alphas_cumprod', t),
@@ -223,9 +249,12 @@ class ConditionOpenAIDenoiser(ConditionDenoiser):
             x0_var = base
         elif ct == 'dps':
             x0_var = torch.zeros(1)
-        else:  # diffpir
+        elif ct == 'diffpir':
             assert self.lambda_ is not None
             x0_var = (s.pow(2) / self.lambda_).reshape(1)
+        else:  # tmpd: sigma^2 * grad_x sum(x0_mean) = sigma^2 * (dx0/dx)^T 1  (condition.py:268-269)
+            ones = torch.ones_like(x)
+            x0_var = self._axpby(self._vjp_x0(ones), float(s.pow(2)), None, 0.0)
         return x0_mean, x0_var, x0_var
 
     def _vjp_x0(self, ghat):

@@ -25,7 +25,7 @@ class GuidedDenoiser:
 
     def __init__(self, sd, cfg, operator, measurement, guidance, x0_cov_type="convert",
                  recon_mse=None, zeta=None, lambda_=None, mle_sigma_thres=0.2,
-                 ortho_tf_type=None, v2=False, tables=None):
+                 ortho_tf_type=None, v2=False, tables=None, eta=None, num_hutchinson_samples=None):
         self.sd, self.cfg = sd, cfg
         self.operator = operator
         self.y, self.y_flatten = measurement
@@ -33,6 +33,7 @@ class GuidedDenoiser:
         self.x0_cov_type = x0_cov_type
         self.recon_mse = recon_mse
         self.zeta, self.lambda_ = zeta, lambda_
+        self.eta, self.num_hutchinson_samples = eta, num_hutchinson_samples
         self.mle_sigma_thres = mle_sigma_thres
         self.ortho_tf_type = ortho_tf_type
         self.ortho_tf = OrthoTransform(ortho_tf_type)
@@ -47,6 +48,8 @@ class GuidedDenoiser:
             return self._uncond_pred_v2(x, sigma)
         D = self.D
         s0 = sigma[:1]
+        if self.x0_cov_type == "tmpd" and not x.requires_grad:
+            x = x.requires_grad_()                                # condition.py:236-237
         c_in = 1 / (s0 ** 2 + 1) ** 0.5                          # external.py:97-100
         t = D.sigma_to_t(sigma).long()                            # condition.py:233 (floor)
         x_in = x * c_in
@@ -78,6 +81,9 @@ class GuidedDenoiser:
             x0_var = torch.zeros(1)
         elif ct == "diffpir":
             x0_var = s0.pow(2) / self.lambda_
+        elif ct == "tmpd":
+            # condition.py:268-269: sigma^2 * grad_x sum(x0_mean) (an extra VJP with an all-ones cotangent)
+            x0_var = grad(x0_mean.sum(), x, retain_graph=True)[0] * s0.pow(2)
         else:
             raise ValueError("Invalid posterior covariance type.")
         return x0_mean, x0_var, x0_var
@@ -117,11 +123,13 @@ class GuidedDenoiser:
 
     def _type_II(self, x, sigma):
         """condition.py:176-183."""
-        with torch.no_grad():
-            x0_mean, x0_var, theta0_var = self.uncond_pred(x, sigma)
+        import contextlib
+        ctx = contextlib.nullcontext() if self.x0_cov_type == "tmpd" else torch.no_grad()
+        with ctx:
+            x0_mean, x0_var, theta0_var = self.uncond_pred(x.detach(), sigma)
             mat = self._solve(x0_mean, x0_var, theta0_var)
             var = x0_var if self.ortho_tf_type is None else theta0_var
-            return x0_mean + self.ortho_tf.inv(self.ortho_tf(mat) * var)
+            return (x0_mean + self.ortho_tf.inv(self.ortho_tf(mat) * var)).detach()
 
     def _dps(self, x, sigma):
         """condition.py:140-148; the 2-norm is per sample in the batched form."""
@@ -152,6 +160,25 @@ class GuidedDenoiser:
             mat = self.mat_solver(self.operator, self.y, x0_mean, x0_var)
             return x0_mean + mat * x0_var
 
+    def _stsl(self, x, sigma, eps_list=None):
+        """condition.py:185-208; per-sample norm and per-sample numel in the batched form.
+        eps_list (optional) supplies the Hutchinson probes instead of torch.randn_like."""
+        assert self.zeta is not None and self.eta is not None and self.num_hutchinson_samples is not None, \
+            "zeta, eta, and num_hutchinson_samples must be specified for STSL guidance"
+        x = x.detach().requires_grad_()
+        x0_mean = self.uncond_pred(x, sigma)[0]
+        diff = self.y - self.operator.forward(x0_mean, noiseless=True)
+        first = -diff.flatten(1).norm(dim=1).sum()
+        second = 0
+        for k in range(self.num_hutchinson_samples):
+            eps = torch.randn_like(x) if eps_list is None else eps_list[k]
+            inc = self.uncond_pred(x + eps, sigma)[0]
+            second = second + -((inc - x0_mean) * eps).sum() * sigma[:1].pow(2)
+        second = second / self.num_hutchinson_samples
+        loss = self.zeta * first + (self.eta / x[0].numel()) * second
+        score = grad(loss.sum(), x)[0]
+        return x0_mean + sigma[:1].pow(2) * score
+
     def __call__(self, x, sigma):
         """ConditionDenoiser.forward (condition.py:83-131)."""
         g = self.guidance
@@ -169,6 +196,10 @@ class GuidedDenoiser:
             hat = self._pgdm(x, sigma)
         elif g == "diffpir":
             hat = self._diffpir(x, sigma)
+        elif g == "stsl":
+            hat = self._stsl(x, sigma, getattr(self, "stsl_eps", None))
+        elif g == "stsl+mle":
+            hat = self._type_I(x, sigma) if low else self._stsl(x, sigma, getattr(self, "stsl_eps", None))
         elif g == "dps+mle":
             hat = self._type_I(x, sigma) if low else self._dps(x, sigma)
         elif g == "pgdm+mle":

@@ -17,6 +17,7 @@ sys.path.insert(0, ROOT)
 from oracle import refimport                                     # noqa: E402
 from oracle import tables as otab, unet as ounet, operators as oops   # noqa: E402
 from oracle import transforms as otf, solvers as osol, condition as ocond, sampling as osamp  # noqa: E402
+from oracle import analytic as oana  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 torch.set_num_threads(8)
@@ -213,6 +214,57 @@ def main():
                 gd_dump[key] = h_r.numpy()
     gd_dump["x0"] = x0.numpy()
     np.savez_compressed(os.path.join(GOLD, "guided_calls.npz"), **gd_dump)
+
+    # ------------------------------------------- tmpd covariance, STSL guidance ----
+    print("[tmpd / stsl, tiny UNet]")
+    ex_dump = {}
+    ex_modes = [("I", "tmpd", {}), ("II", "tmpd", {}), ("stsl", "dps", dict(zeta=1.0, eta=0.5, num_hutchinson_samples=2)),
+                ("stsl+mle", "convert", dict(zeta=1.0, eta=0.5, num_hutchinson_samples=2))]
+    for name in ("gaussian_blur", "inpainting"):
+        for guidance, cov, extra in ex_modes:
+            if cov == "tmpd" and name == "inpainting":
+                # with random weights the TMPD "variance" sigma^2 J^T 1 goes negative; the inpainting system
+                # sigma_s^2 + m*C is then indefinite and CG (scipy or any) is ill-defined -- not a parity case
+                continue
+            for sigma_v in (1.5, 0.12):
+                gx = torch.Generator().manual_seed(11)
+                x = x0 + sigma_v * torch.randn(1, 3, S, S, generator=gx)
+                sigma = torch.tensor([sigma_v])
+                rmodel = cc.ConditionOpenAIDenoiser(
+                    inner_model=model, diffusion=diffusion, x0_cov_type=cov, recon_mse=None,
+                    operator=ref_ops[name], measurement=meas_ref[name], guidance=guidance,
+                    zeta=extra.get("zeta"), eta=extra.get("eta"), num_hutchinson_samples=extra.get("num_hutchinson_samples"),
+                    mle_sigma_thres=0.2, device="cpu").eval()
+                omodel = ocond.GuidedDenoiser(sd, cfg, ora_ops[name], meas_ora[name], guidance, x0_cov_type=cov,
+                                              zeta=extra.get("zeta"), eta=extra.get("eta"),
+                                              num_hutchinson_samples=extra.get("num_hutchinson_samples"), mle_sigma_thres=0.2)
+                torch.manual_seed(5)
+                h_r = rmodel(x.clone(), sigma)
+                torch.manual_seed(5)
+                h_o = omodel(x.clone(), sigma)
+                key = f"{name}|{guidance}|{cov}|{sigma_v}"
+                check(key, h_r, h_o, 5e-4)
+                ex_dump[key] = h_r.numpy()
+    np.savez_compressed(os.path.join(GOLD, "guided_calls_extra.npz"), **ex_dump)
+
+    # ------------------------------------------------- analytic-variance estimator ----
+    print("[analytic variance (OpenAIDenoiser + Monte-Carlo MSE)]")
+    sig_av = ks.get_sigmas_karras(5, 0.01, 80, rho=7.0)
+    batches = [smooth_image(2, S, seed=21), smooth_image(2, S, seed=22)]
+    torch.manual_seed(9)
+    mse_ref = []
+    with torch.no_grad():
+        for sgm in sig_av:
+            m_ = 0
+            for xb in batches:
+                hat = den(xb + torch.randn_like(xb) * sgm, sgm.repeat(2))
+                m_ = m_ + (xb - hat).pow(2).mean()
+            mse_ref.append(m_ / len(batches))
+    mse_ref = torch.stack(mse_ref)
+    torch.manual_seed(9)
+    est = oana.estimate_recon_mse(sd, cfg, batches, sig_av)
+    check("recon_mse list", mse_ref, est["mse_list"], 1e-5)
+    np.savez_compressed(os.path.join(GOLD, "analytic_variance.npz"), sigmas=sig_av.numpy(), mse_list=mse_ref.numpy())
 
     # ------------------------------------------------------- V2 (out_cov head) ----
     print("[V2 calls, ortho_tf=None]")

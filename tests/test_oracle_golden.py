@@ -182,3 +182,30 @@ def test_error_behaviour():
         ocond.GuidedDenoiser(sd, cfg, op, meas, "bogus")(torch.zeros(1, 3, 64, 64), torch.tensor([1.0]))
     with pytest.raises(AssertionError):
         ocond.GuidedDenoiser(sd, cfg, op, meas, "dps", x0_cov_type="dps")(torch.zeros(1, 3, 64, 64), torch.tensor([1.0]))
+
+
+def test_extra_guidance_and_analytic(gold):
+    """tmpd covariance, STSL guidance and the analytic-variance estimator against the reference captures."""
+    from oracle import analytic as oana
+    from helpers import smooth_image
+    g = gold("guided_calls_extra")
+    cfg = ounet.UNetConfig(**ounet.TINY)
+    sd = ounet.init_state_dict(cfg, seed=0)
+    modes = [("I", "tmpd", {}), ("II", "tmpd", {}), ("stsl", "dps", dict(zeta=1.0, eta=0.5, num_hutchinson_samples=2)),
+             ("stsl+mle", "convert", dict(zeta=1.0, eta=0.5, num_hutchinson_samples=2))]
+    for name in ("gaussian_blur", "inpainting"):
+        op, meas, x0 = _ops_and_meas(gold, name)
+        for guidance, cov, extra in modes:
+            for sigma_v in (1.5, 0.12):
+                key = f"{name}|{guidance}|{cov}|{sigma_v}"
+                if key not in g.files:
+                    continue
+                x = x0 + sigma_v * torch.randn(1, 3, 64, 64, generator=torch.Generator().manual_seed(11))
+                m = ocond.GuidedDenoiser(sd, cfg, op, meas, guidance, x0_cov_type=cov, zeta=extra.get("zeta"), eta=extra.get("eta"),
+                                         num_hutchinson_samples=extra.get("num_hutchinson_samples"))
+                torch.manual_seed(5)
+                assert float((m(x, torch.tensor([sigma_v])) - T(g[key])).abs().max()) < 5e-4, key
+    ga = gold("analytic_variance")
+    torch.manual_seed(9)
+    est = oana.estimate_recon_mse(sd, cfg, [smooth_image(2, 64, 21), smooth_image(2, 64, 22)], T(ga["sigmas"]))
+    assert float((est["mse_list"] - T(ga["mse_list"])).abs().max()) < 1e-5

@@ -321,3 +321,57 @@ def test_sampler_golden(gold, tiny):
         from kdip_amd.evaluation import psnr
         dp = abs(float(psnr(x.cpu(), x0)) - float(psnr(ref, x0)))
         assert dp < 1e-3, (sampler, dp)
+
+
+def test_tmpd_stsl_golden(gold, tiny):
+    """tmpd covariance (extra all-ones VJP) and STSL (one forward + VJP per Hutchinson probe) against the
+    reference captures; probes are the same CPU-seeded eps the reference drew."""
+    import kdip_amd.condition as kc
+    models, D, sd, cfg = tiny
+    g = gold("guided_calls_extra")
+    modes = [("I", "tmpd", {}), ("II", "tmpd", {}), ("stsl", "dps", dict(zeta=1.0, eta=0.5, num_hutchinson_samples=2)),
+             ("stsl+mle", "convert", dict(zeta=1.0, eta=0.5, num_hutchinson_samples=2))]
+    for name in ("gaussian_blur", "inpainting"):
+        hop, oop, (y, yf), x0 = make_ops(name, gold)
+        meas = (y.cuda(), yf.cuda())
+        for guidance, cov, extra in modes:
+            for sigma_v in (1.5, 0.12):
+                key = f"{name}|{guidance}|{cov}|{sigma_v}"
+                if key not in g.files:
+                    continue
+                x = x0 + sigma_v * torch.randn(1, 3, 64, 64, generator=torch.Generator().manual_seed(11))
+                m = kc.ConditionOpenAIDenoiser(inner_model=models["f32"], diffusion=D, x0_cov_type=cov, recon_mse=None,
+                                               operator=hop, measurement=meas, guidance=guidance, zeta=extra.get("zeta"),
+                                               eta=extra.get("eta"), num_hutchinson_samples=extra.get("num_hutchinson_samples"),
+                                               mle_sigma_thres=0.2, device="cuda")
+                torch.manual_seed(5)
+                m.stsl_eps = [torch.randn_like(x) for _ in range(extra.get("num_hutchinson_samples") or 0)]
+                hat = m(x.cuda(), torch.tensor([sigma_v], device="cuda")).cpu()
+                err = float((hat - T(g[key])).abs().max())
+                assert err < 3e-3, (key, err)
+
+
+def test_analytic_variance_estimator(gold, tiny):
+    import kdip_amd.analytic_variance as kav
+    from helpers import smooth_image
+    models, D, sd, cfg = tiny
+    ga = gold("analytic_variance")
+    sig = T(ga["sigmas"])
+    batches = [smooth_image(2, 64, 21), smooth_image(2, 64, 22)]
+    # same noise as the reference capture: drawn on the CPU stream in (sigma, batch) order
+    torch.manual_seed(9)
+    noises = [[torch.randn_like(b) for b in batches] for _ in sig]
+    out = []
+    import kdip_amd.external as ke
+    from kdip_amd.sampling import _sigma_vec
+    den = ke.OpenAIDenoiser(models["f32"], D)
+    for i, s in enumerate(sig):
+        acc = 0.0
+        for j, b in enumerate(batches):
+            xt = (b + noises[i][j] * s).cuda()
+            hat = den(xt, _sigma_vec(xt, s)) if float(s) > 0 else xt
+            acc += float((b.cuda() - hat).pow(2).mean())
+        out.append(acc / len(batches))
+    assert float((torch.tensor(out) - T(ga["mse_list"])).abs().max()) < 1e-4
+    res = kav.estimate_recon_mse(models["f32"], D, [b.cuda() for b in batches], sigmas=sig)
+    assert res["mse_list"].shape == (6,) and torch.isfinite(res["mse_list"]).all() and res["errors"].shape == (6, 2)
