@@ -79,6 +79,15 @@ constexpr int KC = 32;            // input channels per B-pipeline stage (one ta
 #ifndef KDIP_BIG
 #define KDIP_BIG 0
 #endif
+#ifndef KDIP_ABL_NOSTAGE
+#define KDIP_ABL_NOSTAGE 0
+#endif
+#ifndef KDIP_ABL_NOB
+#define KDIP_ABL_NOB 0
+#endif
+#ifndef KDIP_ABL_NOEPI
+#define KDIP_ABL_NOEPI 0
+#endif
 #ifndef KDIP_SUBS3
 #define KDIP_SUBS3 1
 #endif
@@ -234,14 +243,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
     // The loop-carried `s_waitcnt vmcnt(0)` hipcc places before the first MFMA of an iteration would
     // also wait for the (HBM-latency) A-stage loads of the next chunk if they were issued first:
     // issue them after the first stage's MFMAs instead (3x3), so only the old B loads are waited for.
-    if (NTAPS * SUBS == 1 && c + 1 < nchunks) stage_load(c + 1);
+    if (!KDIP_ABL_NOSTAGE && NTAPS * SUBS == 1 && c + 1 < nchunks) stage_load(c + 1);
     const unsigned char* abuf = smem + buf * abuf_bytes;
     load_a(aq0, abuf, 0, 0);
 #pragma unroll
     for (int sub = 0; sub < SUBS; ++sub) {
 #pragma unroll
       for (int tap = 0; tap < NTAPS; ++tap) {
-        load_b(bq2, (c * SUBS + sub) * NTAPS + tap + KDIP_B_DEPTH);
+        if (!KDIP_ABL_NOB) load_b(bq2, (c * SUBS + sub) * NTAPS + tap + KDIP_B_DEPTH);
         {
           int ntap = tap + 1, nsub = sub;
           if (ntap == NTAPS) { ntap = 0; nsub = sub + 1; }
@@ -253,7 +262,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) Mma<T>::run(aq0[ks][mt], bq0[ks][nt], acc[mt][nt]);
-        if (NTAPS * SUBS > 1 && sub == 0 && tap == 0 && c + 1 < nchunks) stage_load(c + 1);
+        if (!KDIP_ABL_NOSTAGE && NTAPS * SUBS > 1 && sub == 0 && tap == 0 && c + 1 < nchunks) stage_load(c + 1);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -273,11 +282,24 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
         }
       }
     }
-    if (c + 1 < nchunks) stage_write(buf ^ 1);
-    __syncthreads();
+    if (!KDIP_ABL_NOSTAGE) {
+      if (c + 1 < nchunks) stage_write(buf ^ 1);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: alpha, bias, residual, cast.
+  if (KDIP_ABL_NOEPI) {   // timing ablation: keep every accumulator live, skip the real epilogue
+    float t = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[mt][nt][r];
+    if (t == 12345.678f) ((float*)p.y)[0] = t;
+    return;
+  }
   const T* res = (const T*)p.res;
   if (p.vec_epilogue) {
     // Fast path (Cout % 4 == 0): each wave transposes its fp32 accumulators through LDS so that a
