@@ -88,6 +88,9 @@ constexpr int KC = 32;            // input channels per B-pipeline stage (one ta
 #ifndef KDIP_ABL_NOEPI
 #define KDIP_ABL_NOEPI 0
 #endif
+#ifndef KDIP_EARLY_WRITE
+#define KDIP_EARLY_WRITE 5
+#endif
 #ifndef KDIP_SUBS3
 #define KDIP_SUBS3 1
 #endif
@@ -110,6 +113,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
   constexpr int KCH = KC * SUBS;                       // channels per LDS stage
   constexpr int PIXB = KCH * (int)sizeof(T) + 16;      // padded LDS pixel stride (bytes)
   constexpr int VPP = KCH * (int)sizeof(T) / 16;       // 16-byte vectors per staged pixel
+  constexpr int NST = NTAPS * SUBS;                    // B-pipeline stages per LDS stage
+  // stage index after which the next patch is written to the other LDS buffer (0 = at the chunk end)
+  constexpr int EW_AT = (!KDIP_EARLY_WRITE || NST == 1) ? 0 : (NST >= 9 ? KDIP_EARLY_WRITE : NST / 2);
   constexpr int HALO = (NTAPS == 9) ? 1 : 0;
   constexpr int MAXPIX = (NTAPS == 1) ? BM : ((BM == 256) ? 400 : 256);
   constexpr int MAXV = (MAXPIX * VPP + NTHREADS - 1) / NTHREADS;   // staged 16-byte vectors per thread
@@ -263,6 +269,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) Mma<T>::run(aq0[ks][mt], bq0[ks][nt], acc[mt][nt]);
         if (!KDIP_ABL_NOSTAGE && NTAPS * SUBS > 1 && sub == 0 && tap == 0 && c + 1 < nchunks) stage_load(c + 1);
+        // the other LDS buffer was last read in chunk c-1 (all waves are past that barrier), so the next
+        // patch can be written mid-chunk: its vmcnt wait and ds_writes leave the end-of-chunk critical path
+        if (!KDIP_ABL_NOSTAGE && EW_AT > 0 && sub * NTAPS + tap == EW_AT && c + 1 < nchunks) stage_write(buf ^ 1);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -283,7 +292,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
       }
     }
     if (!KDIP_ABL_NOSTAGE) {
-      if (c + 1 < nchunks) stage_write(buf ^ 1);
+      if (EW_AT == 0 && c + 1 < nchunks) stage_write(buf ^ 1);
       __syncthreads();
     }
   }
