@@ -91,6 +91,9 @@ constexpr int KC = 32;            // input channels per B-pipeline stage (one ta
 #ifndef KDIP_EARLY_WRITE
 #define KDIP_EARLY_WRITE 5
 #endif
+#ifndef KDIP_SETPRIO
+#define KDIP_SETPRIO 0
+#endif
 #ifndef KDIP_SUBS3
 #define KDIP_SUBS3 1
 #endif
@@ -262,12 +265,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
           if (ntap == NTAPS) { ntap = 0; nsub = sub + 1; }
           if (KDIP_A_PREFETCH && nsub < SUBS) load_a(aq1, abuf, nsub, ntap);
         }
+        if (KDIP_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) Mma<T>::run(aq0[ks][mt], bq0[ks][nt], acc[mt][nt]);
+        if (KDIP_SETPRIO) __builtin_amdgcn_s_setprio(0);
         if (!KDIP_ABL_NOSTAGE && NTAPS * SUBS > 1 && sub == 0 && tap == 0 && c + 1 < nchunks) stage_load(c + 1);
         // the other LDS buffer was last read in chunk c-1 (all waves are past that barrier), so the next
         // patch can be written mid-chunk: its vmcnt wait and ds_writes leave the end-of-chunk critical path
@@ -553,6 +558,8 @@ int conv_forward(hipStream_t st, DType dt, int ntaps, const void* x, long ldx, i
   KDIP_REQUIRE(Cin % KC == 0, "conv: Cin=%d must be a multiple of %d (pad the input)", Cin, KC);
   KDIP_REQUIRE(ntaps == 9 || ntaps == 1, "conv: ntaps must be 9 or 1");
   KDIP_REQUIRE((ldx * (dt == DT_BF16 ? 2 : 4)) % 16 == 0, "conv: input channel stride must be 16-byte aligned");
+  KDIP_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)wp % 16) == 0, "conv: input / packed-weight pointers must be 16-byte aligned");
+  KDIP_REQUIRE(B >= 1 && H >= 1 && W >= 1 && Cout >= 1, "conv: empty problem");
   ConvParams p;
   p.x = x; p.ldx = ldx; p.wp = wp; p.bias = bias; p.res = res; p.ldr = ldr; p.y = y; p.ldy = ldy;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.ntilesN = cdiv(Cout, 32);

@@ -698,6 +698,9 @@ int UNet::run(hipStream_t st, const float* x_nchw, const float* t, int B, float 
   CK(ensure_workspace(B));
   have_stash = false;
   CK(forward_impl(st, x_nchw, t, B, in_scale, out_nchw, cov_nchw, feat_nchw));
+  if (persist.peak > persist.cap || scratch.peak > scratch.cap || zeros.peak > zeros.cap)
+    return set_error(KDIP_ERR_STATE, "internal: workspace arena overflow (persist %zu/%zu, scratch %zu/%zu)", persist.peak,
+                     persist.cap, scratch.peak, scratch.cap);
   last_B = B;
   have_stash = true;
   (void)save;
@@ -708,6 +711,8 @@ int UNet::vjp(hipStream_t st, const float* cot_nchw, float* gx_nchw) {
   if (!have_stash) return set_error(KDIP_ERR_STATE, "unet_vjp without a preceding unet_forward");
   size_t mark = persist.off;
   int rc = vjp_impl(st, cot_nchw, gx_nchw);
+  if (!rc && (persist.peak > persist.cap || scratch.peak > scratch.cap || zeros.peak > zeros.cap))
+    rc = set_error(KDIP_ERR_STATE, "internal: workspace arena overflow in the VJP");
   persist.off = mark;   // the stash stays valid: the VJP may be called again (tmpd / STSL style)
   return rc;
 }
