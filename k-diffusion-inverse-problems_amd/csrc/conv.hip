@@ -94,6 +94,9 @@ constexpr int KC = 32;            // input channels per B-pipeline stage (one ta
 #ifndef KDIP_SETPRIO
 #define KDIP_SETPRIO 0
 #endif
+#ifndef KDIP_SUBS1
+#define KDIP_SUBS1 4
+#endif
 #ifndef KDIP_SUBS3
 #define KDIP_SUBS3 1
 #endif
@@ -521,8 +524,8 @@ template <typename T, int NTAPS, int WAVES_M, int WAVES_N, int MT, int NT>
 static int launch_cfg(ConvParams& p, hipStream_t st) {
   if (NTAPS == 1) {
     // 1x1 / linear: stage up to 128 channels per barrier
-    if (sizeof(T) == 2 && p.Cin % 128 == 0) return launch_cfg2<T, NTAPS, WAVES_M, WAVES_N, MT, NT, (NTAPS == 1 ? 4 : 1)>(p, st);
-    if (sizeof(T) == 2 && p.Cin % 64 == 0) return launch_cfg2<T, NTAPS, WAVES_M, WAVES_N, MT, NT, (NTAPS == 1 ? 2 : 1)>(p, st);
+    if (KDIP_SUBS1 >= 4 && sizeof(T) == 2 && p.Cin % 128 == 0) return launch_cfg2<T, NTAPS, WAVES_M, WAVES_N, MT, NT, (NTAPS == 1 ? 4 : 1)>(p, st);
+    if (KDIP_SUBS1 >= 2 && sizeof(T) == 2 && p.Cin % 64 == 0) return launch_cfg2<T, NTAPS, WAVES_M, WAVES_N, MT, NT, (NTAPS == 1 ? 2 : 1)>(p, st);
   }
 #if KDIP_SUBS3 > 1
   if (NTAPS == 9 && sizeof(T) == 2 && MT * NT == 4 && p.Cin % (32 * KDIP_SUBS3) == 0)
