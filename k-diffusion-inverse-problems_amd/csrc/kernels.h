@@ -40,7 +40,7 @@ int gn_stats(hipStream_t st, DType dt, const void* x, long ldx, int B, long HW, 
 // coef[B][C][2] = (a, b) with y = a*x + b  [then SiLU]; a = rstd*gamma*(1+scale), b = (beta - mean*rstd*gamma)*(1+scale)+shift
 // film: [B][2C] fp32 (scale | shift) or null.  Also writes mr[B][32][2] = (mean, rstd) fp32.
 int gn_coef(hipStream_t st, const double* stats, const float* gamma, const float* beta, const float* film,
-            int B, long HW, int C, float eps, float* coef, float* mr);
+            int B, long HW, int C, float eps, float* coef, float* mr, long film_ld = 0);
 int gn_apply(hipStream_t st, DType dt, const void* x, long ldx, const float* coef, int B, long HW, int C, int silu,
              void* y, long ldy);
 // backward: dy wrt apply output -> dx (+ optional addend), two passes.

@@ -100,8 +100,8 @@ int gn_stats(hipStream_t st, DType dt, const void* x, long ldx, int B, long HW, 
 
 // ------------------------------------------------------------------------- coefficients ----
 __global__ void gn_coef_kernel(const double* __restrict__ stats, const float* __restrict__ gamma,
-                               const float* __restrict__ beta, const float* __restrict__ film, int B, long HW, int C,
-                               float eps, float* __restrict__ coef, float* __restrict__ mr) {
+                               const float* __restrict__ beta, const float* __restrict__ film, long film_ld, int B,
+                               long HW, int C, float eps, float* __restrict__ coef, float* __restrict__ mr) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * C) return;
   int b = i / C, c = i % C, cpg = C / 32, g = c / cpg;
@@ -114,7 +114,7 @@ __global__ void gn_coef_kernel(const double* __restrict__ stats, const float* __
   float a = rstd * gamma[c];
   float bb = beta[c] - m * a;
   if (film) {
-    float sc = 1.f + film[(long)b * 2 * C + c], sh = film[(long)b * 2 * C + C + c];
+    float sc = 1.f + film[(long)b * film_ld + c], sh = film[(long)b * film_ld + C + c];
     a *= sc;
     bb = bb * sc + sh;
   }
@@ -124,9 +124,9 @@ __global__ void gn_coef_kernel(const double* __restrict__ stats, const float* __
 }
 
 int gn_coef(hipStream_t st, const double* stats, const float* gamma, const float* beta, const float* film, int B,
-            long HW, int C, float eps, float* coef, float* mr) {
-  hipLaunchKernelGGL(gn_coef_kernel, dim3(cdiv((long)B * C, 256)), dim3(256), 0, st, stats, gamma, beta, film, B, HW, C,
-                     eps, coef, mr);
+            long HW, int C, float eps, float* coef, float* mr, long film_ld) {
+  hipLaunchKernelGGL(gn_coef_kernel, dim3(cdiv((long)B * C, 256)), dim3(256), 0, st, stats, gamma, beta, film,
+                     film_ld ? film_ld : 2L * C, B, HW, C, eps, coef, mr);
   KDIP_LAUNCH_CHECK();
   return KDIP_OK;
 }

@@ -37,7 +37,7 @@ struct Layer {
   std::string prefix;
   int cin, cout, mode;     // mode: 0 none, 1 down, 2 up
   ConvW conv;              // kind 0
-  GnW n1, n2; ConvW c1, c2, skip; LinW emb; bool has_skip = false;   // kind 1
+  GnW n1, n2; ConvW c1, c2, skip; LinW emb; int emb_off = 0; bool has_skip = false;   // kind 1 (emb_off: row offset in emb_all)
   GnW norm; ConvW qkv, proj; int heads = 0;                          // kind 2
   Saved sv;
 };
@@ -61,6 +61,8 @@ struct UNet {
   std::vector<Layer> mid;
   int final_ch = 0;
   LinW te0, te2;
+  LinW emb_all;                     // all ResBlock emb_layers.1 stacked: one launch per forward
+  int emb_total = 0;
   GnW out_norm; ConvW out_conv; ConvW cov_conv; bool has_cov = false;
   std::map<std::string, std::vector<float>> raw;      // host fp32 parameters by reference state_dict name
   std::map<std::string, std::vector<long>> raw_shape;

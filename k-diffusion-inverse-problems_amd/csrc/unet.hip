@@ -189,13 +189,14 @@ int UNet::finalize() {
   const int ted = cfg.model_channels * 4;
   mklin(te0, "time_embed.0", cfg.model_channels, ted);
   mklin(te2, "time_embed.2", ted, ted);
+  std::vector<std::string> emb_names; std::vector<Layer*> emb_layers;
   auto do_layer = [&](Layer& L) {
     const std::string& p = L.prefix;
     if (L.kind == 0) mkconv(L.conv, p, L.cin, L.cout, 9);
     else if (L.kind == 1) {
       mkgn(L.n1, p + ".in_layers.0", L.cin);
       mkconv(L.c1, p + ".in_layers.2", L.cin, L.cout, 9);
-      mklin(L.emb, p + ".emb_layers.1", ted, 2 * L.cout);
+      { L.emb.in = ted; L.emb.out = 2 * L.cout; emb_names.push_back(p + ".emb_layers.1"); emb_layers.push_back(&L); }
       mkgn(L.n2, p + ".out_layers.0", L.cout);
       mkconv(L.c2, p + ".out_layers.3", L.cout, L.cout, 9);
       if (L.has_skip) mkconv(L.skip, p + ".skip_connection", L.cin, L.cout, 1);
@@ -208,6 +209,24 @@ int UNet::finalize() {
   for (auto& b : inp) for (auto& L : b) do_layer(L);
   for (auto& L : mid) do_layer(L);
   for (auto& b : out) for (auto& L : b) do_layer(L);
+  {   // stack all emb_layers.1 weights: [sum 2*cout, ted]
+    emb_total = 0;
+    for (Layer* L : emb_layers) { L->emb_off = emb_total; emb_total += L->emb.out; }
+    std::vector<float> W((size_t)emb_total * ted), Bv(emb_total);
+    for (size_t i = 0; i < emb_layers.size(); ++i) {
+      Layer* L = emb_layers[i];
+      const float* w = need(emb_names[i] + ".weight", (long)L->emb.out * ted);
+      const float* b = need(emb_names[i] + ".bias", L->emb.out);
+      if (!w || !b) break;
+      memcpy(W.data() + (size_t)L->emb_off * ted, w, sizeof(float) * (size_t)L->emb.out * ted);
+      memcpy(Bv.data() + L->emb_off, b, sizeof(float) * L->emb.out);
+    }
+    if (!rc) {
+      emb_all.in = ted; emb_all.out = emb_total;
+      emb_all.w = (float*)upload(W.data(), sizeof(float) * W.size());
+      emb_all.b = (float*)upload(Bv.data(), sizeof(float) * Bv.size());
+    }
+  }
   mkgn(out_norm, "out.0", final_ch);
   mkconv(out_conv, "out.2", final_ch, cfg.out_channels, 9);
   if (raw.count("out_cov.weight")) {
@@ -229,7 +248,7 @@ struct Ctx {
 double* new_sums(Ctx& c, int B) { return (double*)c.u->zeros.alloc(sizeof(double) * B * 64); }
 
 int gn_forward(Ctx& c, const void* x, long ldx, int B, long HW, const GnW& g, const float* film, int silu, void* y,
-               long ldy, float** coef_out, float** mr_out) {
+               long ldy, float** coef_out, float** mr_out, long film_ld = 0) {
   bool dry = c.dry;
   float* coef = (float*)c.u->persist.alloc(sizeof(float) * B * g.C * 2);
   float* mr = (float*)c.u->persist.alloc(sizeof(float) * B * 64);
@@ -240,7 +259,7 @@ int gn_forward(Ctx& c, const void* x, long ldx, int B, long HW, const GnW& g, co
     stats = new_sums(c, B);
     RUN(gn_stats(c.st, c.dt, x, ldx, B, HW, g.C, stats, 1));
   }
-  RUN(gn_coef(c.st, stats, g.gamma, g.beta, film, B, HW, g.C, 1e-5f, coef, mr));
+  RUN(gn_coef(c.st, stats, g.gamma, g.beta, film, B, HW, g.C, 1e-5f, coef, mr, film_ld));
   RUN(gn_apply(c.st, c.dt, x, ldx, coef, B, HW, g.C, silu, y, ldy));
   *coef_out = coef; *mr_out = mr;
   return KDIP_OK;
@@ -325,7 +344,7 @@ static int upsample2s(hipStream_t st, DType dt, const void* x, long ldx, int B, 
 }
 
 // --------------------------------------------------------------------------- forward ----
-static int res_forward(Ctx& c, Layer& L, const void* x, long ldx, int B, int& H, int& W, const float* emb, void** outp) {
+static int res_forward(Ctx& c, Layer& L, const void* x, long ldx, int B, int& H, int& W, const float* film_all, void** outp) {
   bool dry = c.dry;
   UNet* u = c.u;
   const size_t es = c.es;
@@ -355,10 +374,9 @@ static int res_forward(Ctx& c, Layer& L, const void* x, long ldx, int B, int& H,
   void* h2 = u->persist.alloc(es * B * HWo * L.cout);
   L.sv.h2 = h2;
   CK(conv_f(c, L.c1, cin_ptr, L.cin, B, Ho, Wo, h2, L.cout, nullptr, 0, 0, true));
-  float* film = (float*)u->scratch.alloc(sizeof(float) * B * 2 * L.cout);
-  RUN(linear_f32(c.st, emb, L.emb, B, 1, film));
+  const float* film = film_all + L.emb_off;          // row b at film + b * emb_total
   void* h3 = u->scratch.alloc(es * B * HWo * L.cout);
-  CK(gn_forward(c, h2, L.cout, B, HWo, L.n2, film, 1, h3, L.cout, &L.sv.coef2, &L.sv.mr2));
+  CK(gn_forward(c, h2, L.cout, B, HWo, L.n2, film, 1, h3, L.cout, &L.sv.coef2, &L.sv.mr2, u->emb_total));
   const void* S = xs; long ldS = ldxs;
   if (L.has_skip) {
     void* sk = u->scratch.alloc(es * B * HWo * L.cout);
@@ -430,6 +448,8 @@ int UNet::forward_impl(hipStream_t st, const float* x_nchw, const float* t, int 
   RUN(timestep_embedding(st, t, B, mc, temb));
   RUN(linear_f32(st, temb, te0, B, 0, e1));
   RUN(linear_f32(st, e1, te2, B, 1, emb));
+  float* film_all = (float*)persist.alloc(sizeof(float) * (size_t)B * emb_total);
+  RUN(linear_f32(st, emb, emb_all, B, 1, film_all));       // every ResBlock's Linear(SiLU(emb)) in one launch
   // input: NCHW fp32 * c_in -> NHWC T, channels padded to 32
   void* xin = persist.alloc(es * (size_t)B * H * W * 32);
   RUN(nchw_to_nhwc(st, dt, x_nchw, B, cfg.in_channels, H, W, in_scale, xin, 32, 32));
@@ -445,7 +465,7 @@ int UNet::forward_impl(hipStream_t st, const float* x_nchw, const float* t, int 
         L.sv.B = B; L.sv.H = H; L.sv.W = W;
         CK(conv_f(c, L.conv, xin, 32, B, H, W, o, L.cout, nullptr, 0, 0, true));
       } else if (L.kind == 1) {
-        CK(res_forward(c, L, h, ldh, B, H, W, emb, &o));
+        CK(res_forward(c, L, h, ldh, B, H, W, film_all, &o));
       } else {
         CK(attn_forward(c, L, h, ldh, B, H, W, &o));
       }
