@@ -239,15 +239,28 @@ int T_to_f32(hipStream_t st, DType dt, const void* x, long n, float* y) {
   return KDIP_OK;
 }
 
-// NCHW fp32 -> NHWC T with channel padding (pixel-major threads; C is tiny: 3)
+// NCHW fp32 -> NHWC T with channel padding (pixel-major threads; C is tiny: 3 or 6): the padded pixel
+// row is assembled in registers and written with 16-byte stores.
 template <typename T>
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, int B, int C, long HW, float scale, T* __restrict__ y,
                                     long ld, int Cpad) {
+  constexpr int EPV = TypeInfo<T>::EPV;
   long n = (long)B * HW;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     long b = i / HW, p = i % HW;
     T* o = y + i * ld;
-    for (int c = 0; c < Cpad; ++c) o[c] = from_f32<T>(c < C ? x[(b * C + c) * HW + p] * scale : 0.f);
+    if (Cpad % EPV == 0 && C <= 2 * EPV && (ld * (long)sizeof(T)) % 16 == 0) {
+      float f[2 * EPV];
+#pragma unroll
+      for (int c = 0; c < 2 * EPV; ++c) f[c] = c < C ? x[(b * C + c) * HW + p] * scale : 0.f;
+      *(uint4*)o = pack16<T>(f);
+      const int nv = Cpad / EPV;
+      if (nv > 1) *(uint4*)(o + EPV) = pack16<T>(f + EPV);
+      const uint4 z = make_uint4(0, 0, 0, 0);
+      for (int v = 2; v < nv; ++v) *(uint4*)(o + (long)v * EPV) = z;
+    } else {
+      for (int c = 0; c < Cpad; ++c) o[c] = from_f32<T>(c < C ? x[(b * C + c) * HW + p] * scale : 0.f);
+    }
   }
 }
 int nchw_to_nhwc(hipStream_t st, DType dt, const float* x, int B, int C, int H, int W, float scale, void* y, long ld,
