@@ -162,6 +162,10 @@ int kdip_test_conv(void* stream, int dtype, int ntaps, const float* x_nchw_dev, 
 int kdip_test_groupnorm(void* stream, int dtype, const float* x_nchw_dev, int B, int C, int H, int W,
                         const float* gamma_host, const float* beta_host, const float* film_host, int silu,
                         float* y_nchw_dev, const float* dy_nchw_dev, float* dx_nchw_dev);
+/* Diagnostic (libraries built with -DKDIP_TIMING=1 only; KDIP_ERR_UNSUPPORTED otherwise): every later 3x3 conv launch
+ * matching (H, real Cin, Cout, fused-statistics mode) writes per-block phase timestamps (100 MHz ticks: start, first patch
+ * staged, K loop done, end, + 3 epilogue sub-phases) to dev_buf[grid][8] (uint64).  dev_buf = NULL switches it off.  tools/conv_phases.py. */
+int kdip_debug_conv_timing(void* dev_buf, int H, int cin, int cout, int st_mode);
 
 #ifdef __cplusplus
 }

@@ -180,6 +180,8 @@ int kdip_sampler_heun(void* stream, const float* x, const float* d1, const float
 // ------------------------------------------------------------------------- test hooks ----
 static inline int pad32i(int c) { return (c + 31) / 32 * 32; }
 
+int kdip_debug_conv_timing(void* dev_buf, int H, int cin, int cout, int st_mode) { return conv_debug_timing(dev_buf, H, cin, cout, st_mode); }
+
 int kdip_test_conv(void* stream, int dtype, int ntaps, const float* x_nchw, int B, int Cin, int H, int W, const float* w_host,
                    const float* bias_host, int Cout, int transpose_flip, float* y_nchw) {
   hipStream_t st = ST(stream);

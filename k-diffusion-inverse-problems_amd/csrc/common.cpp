@@ -29,7 +29,8 @@ void prof_end(hipStream_t st) {
   g_recs.push_back(g_cur);
 }
 static const char* kClassNames[PC_COUNT] = {"conv3x3_igemm_128x128", "conv3x3_igemm_128x64", "conv3x3_igemm_128x32",
-                                            "conv1x1_igemm_128x128", "conv1x1_igemm_128x64", "conv1x1_igemm_128x32"};
+                                            "conv1x1_igemm_128x128", "conv1x1_igemm_128x64", "conv1x1_igemm_128x32",
+                                            "gn_stats", "gn_apply", "gn_bwd_stats", "gn_bwd_apply"};
 }  // namespace kdip
 
 extern "C" {

@@ -82,18 +82,26 @@ template <typename T> __device__ inline uint4 pack16(const float* in);
 template <> __device__ inline uint4 pack16<float>(const float* in) {
   return make_uint4(__float_as_uint(in[0]), __float_as_uint(in[1]), __float_as_uint(in[2]), __float_as_uint(in[3]));
 }
+// two fp32 -> packed bf16x2 (round-to-nearest-even): one v_cvt_pk_bf16_f32 on gfx950
+__device__ inline uint32_t pack_bf16x2(float lo, float hi) {
+  typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
+  typedef float f32x2_hw __attribute__((ext_vector_type(2)));
+  f32x2_hw v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_hw));
+}
 template <> __device__ inline uint4 pack16<bf16_t>(const float* in) {
-  uint4 r;
-  r.x = (uint32_t)f32_to_bf16(in[0]) | ((uint32_t)f32_to_bf16(in[1]) << 16);
-  r.y = (uint32_t)f32_to_bf16(in[2]) | ((uint32_t)f32_to_bf16(in[3]) << 16);
-  r.z = (uint32_t)f32_to_bf16(in[4]) | ((uint32_t)f32_to_bf16(in[5]) << 16);
-  r.w = (uint32_t)f32_to_bf16(in[6]) | ((uint32_t)f32_to_bf16(in[7]) << 16);
-  return r;
+  return make_uint4(pack_bf16x2(in[0], in[1]), pack_bf16x2(in[2], in[3]), pack_bf16x2(in[4], in[5]), pack_bf16x2(in[6], in[7]));
 }
 
 __device__ inline float silu_f(float z) { return z / (1.f + __expf(-z)); }
 __device__ inline float silu_grad_f(float z) {
   float s = 1.f / (1.f + __expf(-z));
+  return s * (1.f + z * (1.f - s));
+}
+
+// v_rcp_f32 form (1 ulp) for the bf16 pipeline; the f32 parity mode keeps the IEEE division above
+__device__ inline float silu_grad_fast(float z) {
+  float s = __builtin_amdgcn_rcpf(1.f + __expf(-z));
   return s * (1.f + z * (1.f - s));
 }
 
@@ -117,7 +125,8 @@ inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- opt-in per-launch profiler (HIP events on the launch stream; used by bench.py's roofline leg) ----
 enum ProfClass { PC_CONV3_128x128 = 0, PC_CONV3_128x64, PC_CONV3_128x32, PC_CONV1_128x128, PC_CONV1_128x64,
-                 PC_CONV1_128x32, PC_COUNT };
+                 PC_CONV1_128x32, PC_GN_STATS, PC_GN_APPLY, PC_GN_BWD_STATS, PC_GN_BWD_APPLY, PC_COUNT };
+constexpr int PC_NUM_CONV = PC_GN_STATS;      // classes [0, PC_NUM_CONV) are MFMA convs (flops); the rest are HBM streaming passes (bytes)
 extern bool g_prof_on;
 void prof_begin(hipStream_t st, int cls, double flops, double bytes, const char* tag = nullptr, long d0 = 0, long d1 = 0, long d2 = 0, long d3 = 0);
 void prof_end(hipStream_t st);

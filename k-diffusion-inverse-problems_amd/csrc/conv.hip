@@ -39,6 +39,10 @@ template <> struct Mma<float> {
   }
 };
 
+#ifndef KDIP_TIMING
+#define KDIP_TIMING 0      // diagnostic build: per-block phase timestamps (kdip_debug_conv_timing)
+#endif
+
 struct ConvParams {
   const void* x; long ldx;        // input NHWC, channel stride ldx (elements)
   const void* wp;                 // packed weights
@@ -55,6 +59,7 @@ struct ConvParams {
   float alpha;                    // output scale (applied before bias)
   int cin_real;                   // un-padded input channels (profiling / algorithmic FLOPs only)
   int vec_epilogue;               // LDS-transposed 4-channel-per-lane stores
+  int fast_epilogue;              // bf16 out, all strides / pointers 16-byte friendly: 8-channel-per-lane stores (below)
   // fused GroupNorm statistics of the OUTPUT tensor (vector epilogue, one image per tile only):
   //   st_mode 1: sums[b][g] += (sum y, sum y^2)                         -> next GroupNorm forward
   //   st_mode 2: y is dL/d(GN-apply output); with x = the GN input, z = a*x + b:
@@ -64,7 +69,21 @@ struct ConvParams {
   const void* st_x; long st_ldx;  // mode 2
   const float* st_coef;           // mode 2: [B][Cout][2] (a, b)
   const float* st_mr;             // mode 2: [B][32][2] (mean, rstd)
+  unsigned long long* dbg;        // KDIP_TIMING builds: [grid][8] s_memrealtime stamps (start, staged, k-loop done, end, store loop done, sync 1, sync 2)
 };
+
+static unsigned long long* g_conv_dbg = nullptr;
+static int g_dbg_H = 0, g_dbg_cin = 0, g_dbg_cout = 0, g_dbg_mode = 0;
+int conv_debug_timing(void* buf, int H, int cin, int cout, int st_mode) {
+  if (!KDIP_TIMING) return set_error(KDIP_ERR_UNSUPPORTED, "conv timing: library not built with -DKDIP_TIMING=1");
+  g_conv_dbg = (unsigned long long*)buf; g_dbg_H = H; g_dbg_cin = cin; g_dbg_cout = cout; g_dbg_mode = st_mode;
+  return KDIP_OK;
+}
+#if KDIP_TIMING
+#define KDIP_STAMP(i) do { if (p.dbg && threadIdx.x == 0) p.dbg[(long)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define KDIP_STAMP(i) do { } while (0)
+#endif
 
 constexpr int KC = 32;            // input channels per B-pipeline stage (one tap of one 32-channel sub-chunk)
 #ifndef KDIP_B_DEPTH
@@ -88,6 +107,12 @@ constexpr int KC = 32;            // input channels per B-pipeline stage (one ta
 #ifndef KDIP_ABL_NOEPI
 #define KDIP_ABL_NOEPI 0
 #endif
+#ifndef KDIP_ABL_NOATOM
+#define KDIP_ABL_NOATOM 0
+#endif
+#ifndef KDIP_FAST_EPI
+#define KDIP_FAST_EPI 1
+#endif
 #ifndef KDIP_EARLY_WRITE
 #define KDIP_EARLY_WRITE 5
 #endif
@@ -106,6 +131,150 @@ constexpr int KC = 32;            // input channels per B-pipeline stage (one ta
 #ifndef KDIP_OCC
 #define KDIP_OCC 3
 #endif
+
+
+// ---- bf16 fast epilogue ------------------------------------------------------------------
+// One code path per (residual, statistics mode), no branches inside: the wave transposes its fp32
+// accumulators through LDS so a lane owns 8 consecutive channels of one pixel (16-byte stores), and
+// the residual / GroupNorm-input rows of a whole m-tile are fetched BEFORE the transpose so their
+// HBM latency overlaps the LDS traffic (with the loads inside the store loop, behind uniform
+// branches, every pass paid a full memory round trip: 19-23 us of a 38 us block lifetime).
+template <int WAVES_M, int WAVES_N, int MT, int NT, bool RES, int MODE>
+__device__ __forceinline__ void epilogue_bf16_fast(const ConvParams& p, f32x16 (&acc)[MT][NT], unsigned char* smem, int tid,
+                                                   int lane, int wave, int wm, int wn, int nt0, int ntb, int img0, int y0,
+                                                   int x0) {
+  constexpr int BN = WAVES_N * NT * 32;
+  constexpr int RS = NT * 32 * 4 + 16;               // fp32 row stride of the per-wave region
+  constexpr int LPR = NT * 4;                        // lanes (8-channel vectors) per pixel row
+  constexpr int RPI = 64 / LPR;                      // pixel rows per pass
+  constexpr int NPASS = 32 / RPI;
+  unsigned char* creg = smem + wave * 32 * RS;
+  float* sred = (float*)(smem + WAVES_M * WAVES_N * 32 * RS);     // [BN/4][2] block-level stats combine
+  const int vec = lane % LPR, rowl = lane / LPR;
+  const int nl = nt0 * 32 + vec * 8;                 // this lane's 8 output channels
+  const int cpg = p.Cout >> 5;
+  const bf16_t* res = (const bf16_t*)p.res;
+  const bf16_t* sx = (const bf16_t*)p.st_x;
+  bf16_t* yout = (bf16_t*)p.y;
+  float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};      // per 4-channel half (cpg % 4 == 0: a half never straddles groups)
+  if (MODE) {
+    if (tid < BN / 4 * 2) sred[tid] = 0.f;
+  }
+  float bv[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bv[nt] = p.bias ? p.bias[(nt0 + nt) * 32 + (lane & 31)] : 0.f;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int pix[NPASS];                                  // pixel index (B*H*W < 2^31)
+    uint4 rres[NPASS];
+#pragma unroll
+    for (int it = 0; it < NPASS; ++it) {
+      const int m = (wm * MT + mt) * 32 + it * RPI + rowl;
+      const int tb = m >> p.lgTHW, rr = m & ((1 << p.lgTHW) - 1);
+      const int ty = rr >> p.lgTW, tx = rr & (p.TW - 1);
+      pix[it] = ((img0 + tb) * p.H + (y0 + ty)) * p.W + (x0 + tx);
+      if (RES) rres[it] = *(const uint4*)(res + (long)pix[it] * p.ldr + nl);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        *(float*)(creg + row * RS + (nt * 32 + (lane & 31)) * 4) = acc[mt][nt][r] * p.alpha + bv[nt];
+      }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+    for (int it = 0; it < NPASS; ++it) {
+      const int row = it * RPI + rowl;
+      const float4 v0 = *(const float4*)(creg + row * RS + vec * 32), v1 = *(const float4*)(creg + row * RS + vec * 32 + 16);
+      float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      if (RES) {
+        float rf[8];
+        unpack16<bf16_t>(rres[it], rf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rf[e];
+      }
+      const uint4 o = pack16<bf16_t>(v);
+      *(uint4*)(yout + (long)pix[it] * p.ldy + nl) = o;
+      if (MODE == 1) {
+        float vv[8];
+        unpack16<bf16_t>(o, vv);                      // statistics of the stored (rounded) values
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[e >> 2] += vv[e]; s2[e >> 2] += vv[e] * vv[e]; }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+  if (MODE == 2) {
+    // GroupNorm-backward sums in a second sweep, once the accumulators are dead (folding it into the store
+    // passes needs > 256 VGPRs).  Every lane re-reads exactly the dy values it stored itself (program order,
+    // L2-hot) next to the x rows, 4 passes per batch in flight.
+    float ca[8], cb[8], gm[2], gr[2];
+    const float4* cf = (const float4*)(p.st_coef + ((long)img0 * p.Cout + nl) * 2);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 c = cf[q];
+      ca[2 * q] = c.x; cb[2 * q] = c.y; ca[2 * q + 1] = c.z; cb[2 * q + 1] = c.w;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float2 m = *(const float2*)(p.st_mr + ((long)img0 * 32 + (nl + 4 * h) / cpg) * 2);
+      gm[h] = m.x; gr[h] = m.y;
+    }
+    constexpr int SB = (MT * NPASS) % 4 == 0 ? 4 : (MT * NPASS) % 2 == 0 ? 2 : 1;   // passes per batch
+#pragma unroll 1
+    for (int q0 = 0; q0 < MT * NPASS; q0 += SB) {
+      uint4 rd[SB], rx[SB];
+#pragma unroll
+      for (int j = 0; j < SB; ++j) {
+        const int m = wm * MT * 32 + (q0 + j) * RPI + rowl;
+        const int tb = m >> p.lgTHW, rr = m & ((1 << p.lgTHW) - 1);
+        const int ty = rr >> p.lgTW, tx = rr & (p.TW - 1);
+        const long px = ((long)(img0 + tb) * p.H + (y0 + ty)) * p.W + (x0 + tx);
+        rd[j] = *(const uint4*)(yout + px * p.ldy + nl);
+        rx[j] = *(const uint4*)(sx + px * p.st_ldx + nl);
+      }
+#pragma unroll
+      for (int j = 0; j < SB; ++j) {
+        float vv[8], xv[8];
+        unpack16<bf16_t>(rd[j], vv);
+        unpack16<bf16_t>(rx[j], xv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float z = ca[e] * xv[e] + cb[e];
+          const float dz = p.st_silu ? vv[e] * silu_grad_fast(z) : vv[e];
+          const float adz = ca[e] * dz;
+          s1[e >> 2] += adz;
+          s2[e >> 2] += adz * xv[e];                  // sum a*dz*x; centred and scaled once per lane below
+        }
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) s2[h] = (s2[h] - gm[h] * s1[h]) * gr[h];     // sum a*dz*xhat over this lane's <= 64 values
+  }
+  if (MODE) {
+    // rows -> lanes sharing `vec`; then waves -> LDS; then one fp64 atomic pair per 4-channel vector
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) { s1[h] += __shfl_xor(s1[h], o, 64); s2[h] += __shfl_xor(s2[h], o, 64); }
+    __syncthreads();                                  // sred zeroed, all waves past their creg use
+    if (lane < LPR) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        atomicAdd(&sred[(wn * NT * 8 + lane * 2 + h) * 2], s1[h]);
+        atomicAdd(&sred[(wn * NT * 8 + lane * 2 + h) * 2 + 1], s2[h]);
+      }
+    }
+    __syncthreads();
+    if (tid < BN / 4) {
+      const int n = ntb * BN + tid * 4;
+      double* dst = p.st_sums + ((long)img0 * 32 + n / cpg) * 2;
+      atomicAdd(dst, (double)sred[tid * 2]);
+      atomicAdd(dst + 1, (double)sred[tid * 2 + 1]);
+    }
+  }
+}
 
 // SUBS = 32-channel sub-chunks staged in LDS per barrier (1 for 3x3; up to 4 for 1x1 so a barrier
 // covers 32 MFMAs per wave instead of 8).
@@ -127,6 +296,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
   constexpr int MAXV = (MAXPIX * VPP + NTHREADS - 1) / NTHREADS;   // staged 16-byte vectors per thread
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
+  KDIP_STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63;
   // wave index made provably wave-uniform: everything derived from it (weight-fragment base
   // pointers, LDS regions) then lives in SGPRs and the B loads use the saddr + lane-offset form.
@@ -223,6 +393,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
   stage_load(0);
   stage_write(0);
   __syncthreads();
+  KDIP_STAMP(1);
 
   // B fragments are software-pipelined two stages (= one tap of one 32-channel sub-chunk) ahead in
   // registers; a stage index past the end is clamped to the last stage (one redundant L2 hit) so the
@@ -305,6 +476,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
     }
   }
 
+  KDIP_STAMP(2);
   // ---- epilogue: alpha, bias, residual, cast.
   if (KDIP_ABL_NOEPI) {   // timing ablation: keep every accumulator live, skip the real epilogue
     float t = 0.f;
@@ -316,6 +488,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
         for (int r = 0; r < 16; ++r) t += acc[mt][nt][r];
     if (t == 12345.678f) ((float*)p.y)[0] = t;
     return;
+  }
+  if constexpr (sizeof(T) == 2) {
+    if (p.fast_epilogue && (ntb + 1) * BN <= p.Cout) {       // block-uniform
+#define KDIP_EPI(R, M) epilogue_bf16_fast<WAVES_M, WAVES_N, MT, NT, R, M>(p, acc, smem, tid, lane, wave, wm, wn, nt0, ntb, img0, y0, x0)
+      if (p.res) {
+        if (p.st_mode == 0) KDIP_EPI(true, 0); else if (p.st_mode == 1) KDIP_EPI(true, 1); else KDIP_EPI(true, 2);
+      } else {
+        if (p.st_mode == 0) KDIP_EPI(false, 0); else if (p.st_mode == 1) KDIP_EPI(false, 1); else KDIP_EPI(false, 2);
+      }
+#undef KDIP_EPI
+      KDIP_STAMP(3);
+      return;
+    }
   }
   const T* res = (const T*)p.res;
   if (p.vec_epilogue) {
@@ -414,25 +599,33 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
+    KDIP_STAMP(4);
     if (p.st_mode) {
       // rows -> lanes sharing `vec`; then waves -> LDS; then one fp64 atomic pair per 4-channel vector
 #pragma unroll
       for (int o = LPR; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
       __syncthreads();                                  // sred zeroed, all waves past their creg use
+      KDIP_STAMP(5);
       if (lane < LPR) {
         atomicAdd(&sred[(wn * LPR + lane) * 2], s1);
         atomicAdd(&sred[(wn * LPR + lane) * 2 + 1], s2);
       }
       __syncthreads();
+      KDIP_STAMP(6);
       if (tid < BN / 4) {
         const int n = ntb * BN + tid * 4;
         if (n < p.Cout && img0 < p.B) {
           double* dst = p.st_sums + ((long)img0 * 32 + n / cpg) * 2;
+#if !KDIP_ABL_NOATOM
           atomicAdd(dst, (double)sred[tid * 2]);
           atomicAdd(dst + 1, (double)sred[tid * 2 + 1]);
+#else
+          if (sred[tid * 2] == 12345.678f) dst[0] = sred[tid * 2 + 1];
+#endif
         }
       }
     }
+    KDIP_STAMP(3);
     return;
   }
   // Generic path (ragged Cout, e.g. the 6- and 3-channel heads): MFMA layout, scalar stores.
@@ -496,11 +689,16 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
     size_t cl = (size_t)WAVES_M * WAVES_N * 32 * (NT * 32 * 4 + 16) + (size_t)BN / 4 * 2 * sizeof(float);
     if (cl > lds) lds = cl;
   }
+  p.fast_epilogue = KDIP_FAST_EPI && sizeof(T) == 2 && !p.out_f32 && p.vec_epilogue && p.Cout % 8 == 0 && p.ldy % 8 == 0 && (uintptr_t)p.y % 16 == 0 &&
+                    (!p.res || (p.ldr % 8 == 0 && (uintptr_t)p.res % 16 == 0)) && p.B % TB == 0 &&
+                    (p.st_mode != 2 || (p.st_ldx % 8 == 0 && (uintptr_t)p.st_x % 16 == 0 && (uintptr_t)p.st_coef % 16 == 0 && (uintptr_t)p.st_mr % 8 == 0));
   if (p.st_mode && !(p.vec_epilogue && TB == 1 && p.Cout % 32 == 0 && ((p.Cout >> 5) % 4) == 0))
     return set_error(KDIP_ERR_UNSUPPORTED, "conv: fused GroupNorm statistics not available for this shape");
   int nblkN = cdiv(p.ntilesN * 32, BN);
   long grid = (long)p.mtiles * nblkN;
   auto kern = conv_igemm_kernel<T, NTAPS, WAVES_M, WAVES_N, MT, NT, SUBS>;
+  p.dbg = (KDIP_TIMING && g_conv_dbg && NTAPS == 9 && p.H == g_dbg_H && p.cin_real == g_dbg_cin && p.Cout == g_dbg_cout &&
+           p.st_mode == g_dbg_mode && grid <= 16384) ? g_conv_dbg : nullptr;
   if (g_prof_on) {
     const int cls = (NTAPS == 9 ? 0 : 3) + (BN == 128 ? 0 : (BN == 64 ? 1 : 2));
     const double px = (double)p.B * p.H * p.W;
@@ -536,6 +734,9 @@ static int launch_cfg(ConvParams& p, hipStream_t st) {
 
 template <typename T, int NTAPS>
 static int launch_T(ConvParams& p, hipStream_t st) {
+#ifdef KDIP_ONLY_MAIN     // compile-time experiments: one tile configuration only
+  return launch_cfg<T, NTAPS, 2, 2, 2, 2>(p, st);
+#endif
   const int npad = p.ntilesN * 32;
   // All tiles are 128 pixels tall; pick the widest N tile that still gives >= 2 blocks per CU.
   // Small-spatial layers (8x8 ... 32x32) are weight-streaming / latency bound: more, narrower

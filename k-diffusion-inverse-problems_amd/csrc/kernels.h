@@ -18,6 +18,7 @@ int conv_forward(hipStream_t st, DType dt, int ntaps, const void* x, long ldx, i
                  const void* wp, const float* bias, int Cout, void* y, long ldy, const void* res, long ldr,
                  int out_f32, float alpha, int cin_real = 0, const ConvStats* stt = nullptr);
 size_t packed_weight_bytes(DType dt, int ntaps, int Cin_pad, int Cout);
+int conv_debug_timing(void* buf, int H, int cin, int cout, int st_mode);   // -DKDIP_TIMING=1 diagnostic builds only
 void pack_conv_weight(DType dt, const float* w, int Cout, int Cin, int ntaps, int transpose_flip, int Cin_pad_out,
                       void* out);
 

@@ -83,6 +83,7 @@ int gn_stats(hipStream_t st, DType dt, const void* x, long ldx, int B, long HW, 
   if (!prezeroed) KDIP_HIP_CHECK(hipMemsetAsync(stats, 0, sizeof(double) * B * 64, st));
   long chunk = pick_chunk(HW, B);
   dim3 grid(cdiv(HW, chunk), B);
+  prof_begin(st, PC_GN_STATS, 0, (double)B * HW * C * (dt == DT_BF16 ? 2.0 : 4.0), "gn", B, HW, C, 0);
   if (dt == DT_BF16) {
     KDIP_REQUIRE(C % 8 == 0 && C / 8 <= 1024, "groupnorm: unsupported C=%d", C);
     GnGeom g = gn_geom<bf16_t>(C);
@@ -94,6 +95,7 @@ int gn_stats(hipStream_t st, DType dt, const void* x, long ldx, int B, long HW, 
     hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(g.nthreads), 0, st, (const float*)x, ldx, HW, C, g.VP,
                        g.lanes, g.cpg, chunk, stats);
   }
+  prof_end(st);
   KDIP_LAUNCH_CHECK();
   return KDIP_OK;
 }
@@ -173,6 +175,7 @@ int gn_apply(hipStream_t st, DType dt, const void* x, long ldx, const float* coe
              void* y, long ldy) {
   long chunk = pick_chunk_stream(HW, B);
   dim3 grid(cdiv(HW, chunk), B);
+  prof_begin(st, PC_GN_APPLY, 0, 2.0 * B * HW * C * (dt == DT_BF16 ? 2.0 : 4.0), "gn", B, HW, C, 0);
   if (dt == DT_BF16) {
     GnGeom g = gn_geom<bf16_t>(C);
     hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(g.nthreads), 0, st, (const bf16_t*)x, ldx, coef, HW, C, g.VP,
@@ -182,6 +185,7 @@ int gn_apply(hipStream_t st, DType dt, const void* x, long ldx, const float* coe
     hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(g.nthreads), 0, st, (const float*)x, ldx, coef, HW, C, g.VP,
                        g.lanes, chunk, silu, (float*)y, ldy);
   }
+  prof_end(st);
   KDIP_LAUNCH_CHECK();
   return KDIP_OK;
 }
@@ -242,6 +246,7 @@ int gn_bwd_stats(hipStream_t st, DType dt, const void* x, long ldx, const void* 
   if (!prezeroed) KDIP_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * B * 64, st));
   long chunk = pick_chunk(HW, B);
   dim3 grid(cdiv(HW, chunk), B);
+  prof_begin(st, PC_GN_BWD_STATS, 0, 2.0 * B * HW * C * (dt == DT_BF16 ? 2.0 : 4.0), "gn", B, HW, C, 0);
   if (dt == DT_BF16) {
     GnGeom g = gn_geom<bf16_t>(C);
     hipLaunchKernelGGL(gn_bwd_stats_kernel<bf16_t>, grid, dim3(g.nthreads), 0, st, (const bf16_t*)x, ldx,
@@ -251,6 +256,7 @@ int gn_bwd_stats(hipStream_t st, DType dt, const void* x, long ldx, const void* 
     hipLaunchKernelGGL(gn_bwd_stats_kernel<float>, grid, dim3(g.nthreads), 0, st, (const float*)x, ldx,
                        (const float*)dy, lddy, coef, mr, HW, C, g.VP, g.lanes, g.cpg, chunk, silu, sums);
   }
+  prof_end(st);
   KDIP_LAUNCH_CHECK();
   return KDIP_OK;
 }
@@ -304,6 +310,7 @@ int gn_bwd_apply(hipStream_t st, DType dt, const void* x, long ldx, const void* 
                  void* dx, long lddx) {
   long chunk = pick_chunk_stream(HW, B);
   dim3 grid(cdiv(HW, chunk), B);
+  prof_begin(st, PC_GN_BWD_APPLY, 0, (addend ? 4.0 : 3.0) * B * HW * C * (dt == DT_BF16 ? 2.0 : 4.0), "gn", B, HW, C, addend ? 1 : 0);
   if (dt == DT_BF16) {
     GnGeom g = gn_geom<bf16_t>(C);
     hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, grid, dim3(g.nthreads), 0, st, (const bf16_t*)x, ldx,
@@ -315,6 +322,7 @@ int gn_bwd_apply(hipStream_t st, DType dt, const void* x, long ldx, const void* 
                        (const float*)dy, lddy, coef, mr, sums, HW, C, g.VP, g.lanes, g.cpg, chunk, silu,
                        (const float*)addend, lda, (float*)dx, lddx);
   }
+  prof_end(st);
   KDIP_LAUNCH_CHECK();
   return KDIP_OK;
 }
