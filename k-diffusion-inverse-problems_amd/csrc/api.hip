@@ -227,14 +227,23 @@ int kdip_test_groupnorm(void* stream, int dtype, const float* x_nchw, int B, int
   KDIP_HIP_CHECK(hipMemcpy(beta, beta_host, 4 * C, hipMemcpyHostToDevice));
   if (film_host) { KDIP_HIP_CHECK(hipMalloc((void**)&film, 8 * B * C)); KDIP_HIP_CHECK(hipMemcpy(film, film_host, 8 * B * C, hipMemcpyHostToDevice)); }
   int rc = nchw_to_nhwc(st, dt, x_nchw, B, C, H, W, 1.f, x, C, C);
-  if (!rc) rc = gn_stats(st, dt, x, C, B, HW, C, stats);
-  if (!rc) rc = gn_coef(st, stats, gamma, beta, film, B, HW, C, 1e-5f, coef, mr);
-  if (!rc) rc = gn_apply(st, dt, x, C, coef, B, HW, C, silu, y, C);
+  const bool small = gn_small_eligible(dt, HW, C);      // same choice as the UNet executor
+  if (small) {
+    if (!rc) rc = gn_fwd_small(st, dt, x, C, B, HW, C, gamma, beta, film, 0, 1e-5f, silu, y, C, coef, mr);
+  } else {
+    if (!rc) rc = gn_stats(st, dt, x, C, B, HW, C, stats);
+    if (!rc) rc = gn_coef(st, stats, gamma, beta, film, B, HW, C, 1e-5f, coef, mr);
+    if (!rc) rc = gn_apply(st, dt, x, C, coef, B, HW, C, silu, y, C);
+  }
   if (!rc) rc = nhwc_T_to_nchw_f32(st, dt, y, C, B, C, H, W, y_nchw);
   if (!rc && dy_nchw && dx_nchw) {
     rc = nchw_to_nhwc(st, dt, dy_nchw, B, C, H, W, 1.f, dy, C, C);
-    if (!rc) rc = gn_bwd_stats(st, dt, x, C, dy, C, coef, mr, B, HW, C, silu, sums);
-    if (!rc) rc = gn_bwd_apply(st, dt, x, C, dy, C, coef, mr, sums, B, HW, C, silu, nullptr, 0, dx, C);
+    if (small) {
+      if (!rc) rc = gn_bwd_small(st, dt, x, C, dy, C, coef, mr, B, HW, C, silu, nullptr, 0, dx, C);
+    } else {
+      if (!rc) rc = gn_bwd_stats(st, dt, x, C, dy, C, coef, mr, B, HW, C, silu, sums);
+      if (!rc) rc = gn_bwd_apply(st, dt, x, C, dy, C, coef, mr, sums, B, HW, C, silu, nullptr, 0, dx, C);
+    }
     if (!rc) rc = nhwc_T_to_nchw_f32(st, dt, dx, C, B, C, H, W, dx_nchw);
   }
   hipError_t e = hipStreamSynchronize(st);

@@ -327,4 +327,170 @@ int gn_bwd_apply(hipStream_t st, DType dt, const void* x, long ldx, const void* 
   return KDIP_OK;
 }
 
+// ------------------------------------------------------------- small feature maps ----
+// HW <= 1024 (the 8x8 ... 32x32 levels): the whole (image, group) slab is a few KB, so the
+// stats / coef / apply chain (3 launches forward, 2 backward, each launch-latency bound at
+// 10-40 us) collapses into one block per (image, group) that reads its slab twice (second
+// read from L1/L2).  Same arithmetic as the streaming kernels above.
+constexpr int GN_SMALL_MAX_CPG = 128;
+
+__device__ inline void block_sum2_d(double& a, double& b, double (*red)[2]) {
+  a = wave_sum_d(a); b = wave_sum_d(b);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[w][0] = a; red[w][1] = b; }
+  __syncthreads();
+  a = 0; b = 0;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { a += red[i][0]; b += red[i][1]; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_fwd_small_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ film,
+                                                           long film_ld, int HW, int C, int cpg, float eps, int silu,
+                                                           T* __restrict__ y, long ldy, float* __restrict__ coef,
+                                                           float* __restrict__ mr) {
+  constexpr int EPV = TypeInfo<T>::EPV;
+  __shared__ double red[4][2];
+  __shared__ float sa[GN_SMALL_MAX_CPG], sb[GN_SMALL_MAX_CPG];
+  const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int vpg = cpg / EPV, nvec = HW * vpg;
+  const T* xb = x + (long)b * HW * ldx + (long)g * cpg;
+  float s = 0.f, ss = 0.f;
+  for (int i = tid; i < nvec; i += 256) {
+    const int px = i / vpg, v = i - px * vpg;
+    float f[EPV];
+    unpack16<T>(*(const uint4*)(xb + (long)px * ldx + v * EPV), f);
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) { s += f[e]; ss += f[e] * f[e]; }
+  }
+  double ds = s, dss = ss;
+  block_sum2_d(ds, dss, red);
+  const double n = (double)HW * cpg;
+  const double mean = ds / n;
+  double var = dss / n - mean * mean;
+  if (var < 0) var = 0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps)), m = (float)mean;
+  if (tid < cpg) {
+    const int c = g * cpg + tid;
+    float a = rstd * gamma[c];
+    float bb = beta[c] - m * a;
+    if (film) {
+      const float sc = 1.f + film[(long)b * film_ld + c], sh = film[(long)b * film_ld + C + c];
+      a *= sc;
+      bb = bb * sc + sh;
+    }
+    sa[tid] = a; sb[tid] = bb;
+    coef[((long)b * C + c) * 2] = a;
+    coef[((long)b * C + c) * 2 + 1] = bb;
+  }
+  if (tid == 0) { mr[((long)b * 32 + g) * 2] = m; mr[((long)b * 32 + g) * 2 + 1] = rstd; }
+  __syncthreads();
+  T* yb = y + (long)b * HW * ldy + (long)g * cpg;
+  for (int i = tid; i < nvec; i += 256) {
+    const int px = i / vpg, v = i - px * vpg;
+    float f[EPV];
+    unpack16<T>(*(const uint4*)(xb + (long)px * ldx + v * EPV), f);
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+      const float z = sa[v * EPV + e] * f[e] + sb[v * EPV + e];
+      f[e] = silu ? silu_f(z) : z;
+    }
+    *(uint4*)(yb + (long)px * ldy + v * EPV) = pack16<T>(f);
+  }
+}
+
+bool gn_small_eligible(DType dt, long HW, int C) {
+  const int cpg = C / 32, epv = dt == DT_BF16 ? 8 : 4;
+  return HW <= 1024 && C % 32 == 0 && cpg % epv == 0 && cpg <= GN_SMALL_MAX_CPG;
+}
+
+int gn_fwd_small(hipStream_t st, DType dt, const void* x, long ldx, int B, long HW, int C, const float* gamma,
+                 const float* beta, const float* film, long film_ld, float eps, int silu, void* y, long ldy, float* coef,
+                 float* mr) {
+  KDIP_REQUIRE(gn_small_eligible(dt, HW, C), "groupnorm(small): unsupported shape HW=%ld C=%d", HW, C);
+  dim3 grid(32, B);
+  prof_begin(st, PC_GN_APPLY, 0, 2.0 * B * HW * C * (dt == DT_BF16 ? 2.0 : 4.0), "gn_small", B, HW, C, 0);
+  if (dt == DT_BF16)
+    hipLaunchKernelGGL(gn_fwd_small_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, ldx, gamma, beta, film,
+                       film_ld ? film_ld : 2L * C, (int)HW, C, C / 32, eps, silu, (bf16_t*)y, ldy, coef, mr);
+  else
+    hipLaunchKernelGGL(gn_fwd_small_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ldx, gamma, beta, film,
+                       film_ld ? film_ld : 2L * C, (int)HW, C, C / 32, eps, silu, (float*)y, ldy, coef, mr);
+  prof_end(st);
+  KDIP_LAUNCH_CHECK();
+  return KDIP_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_small_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy, long lddy,
+                                                           const float* __restrict__ coef, const float* __restrict__ mr, int HW,
+                                                           int C, int cpg, int silu, const T* __restrict__ addend, long lda,
+                                                           T* __restrict__ dx, long lddx) {
+  constexpr int EPV = TypeInfo<T>::EPV;
+  __shared__ double red[4][2];
+  __shared__ float sa[GN_SMALL_MAX_CPG], sb[GN_SMALL_MAX_CPG];
+  const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int vpg = cpg / EPV, nvec = HW * vpg;
+  if (tid < cpg) {
+    sa[tid] = coef[((long)b * C + g * cpg + tid) * 2];
+    sb[tid] = coef[((long)b * C + g * cpg + tid) * 2 + 1];
+  }
+  const float mean = mr[((long)b * 32 + g) * 2], rstd = mr[((long)b * 32 + g) * 2 + 1];
+  __syncthreads();
+  const T* xb = x + (long)b * HW * ldx + (long)g * cpg;
+  const T* db = dy + (long)b * HW * lddy + (long)g * cpg;
+  float t1 = 0.f, t2 = 0.f;
+  for (int i = tid; i < nvec; i += 256) {
+    const int px = i / vpg, v = i - px * vpg;
+    float fx[EPV], fd[EPV];
+    unpack16<T>(*(const uint4*)(xb + (long)px * ldx + v * EPV), fx);
+    unpack16<T>(*(const uint4*)(db + (long)px * lddy + v * EPV), fd);
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+      const float a = sa[v * EPV + e], z = a * fx[e] + sb[v * EPV + e];
+      const float dz = silu ? fd[e] * silu_grad_f(z) : fd[e];
+      const float adz = a * dz;
+      t1 += adz;
+      t2 += adz * (fx[e] - mean) * rstd;
+    }
+  }
+  double d1 = t1, d2 = t2;
+  block_sum2_d(d1, d2, red);
+  const float invN = 1.f / ((float)HW * (float)cpg);
+  const float k1 = rstd * ((float)d2 * invN), k0 = (float)d1 * invN - mean * k1;
+  const T* ab = addend ? addend + (long)b * HW * lda + (long)g * cpg : nullptr;
+  T* ob = dx + (long)b * HW * lddx + (long)g * cpg;
+  for (int i = tid; i < nvec; i += 256) {
+    const int px = i / vpg, v = i - px * vpg;
+    float fx[EPV], fd[EPV], fa[EPV], out[EPV];
+    unpack16<T>(*(const uint4*)(xb + (long)px * ldx + v * EPV), fx);
+    unpack16<T>(*(const uint4*)(db + (long)px * lddy + v * EPV), fd);
+    if (ab) unpack16<T>(*(const uint4*)(ab + (long)px * lda + v * EPV), fa);
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+      const float a = sa[v * EPV + e], z = a * fx[e] + sb[v * EPV + e];
+      const float dz = silu ? fd[e] * silu_grad_f(z) : fd[e];
+      const float r = a * dz - (k0 + k1 * fx[e]);
+      out[e] = ab ? r + fa[e] : r;
+    }
+    *(uint4*)(ob + (long)px * lddx + v * EPV) = pack16<T>(out);
+  }
+}
+
+int gn_bwd_small(hipStream_t st, DType dt, const void* x, long ldx, const void* dy, long lddy, const float* coef,
+                 const float* mr, int B, long HW, int C, int silu, const void* addend, long lda, void* dx, long lddx) {
+  KDIP_REQUIRE(gn_small_eligible(dt, HW, C), "groupnorm(small) backward: unsupported shape HW=%ld C=%d", HW, C);
+  dim3 grid(32, B);
+  prof_begin(st, PC_GN_BWD_APPLY, 0, (addend ? 4.0 : 3.0) * B * HW * C * (dt == DT_BF16 ? 2.0 : 4.0), "gn_small", B, HW, C, addend ? 1 : 0);
+  if (dt == DT_BF16)
+    hipLaunchKernelGGL(gn_bwd_small_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, coef,
+                       mr, (int)HW, C, C / 32, silu, (const bf16_t*)addend, lda, (bf16_t*)dx, lddx);
+  else
+    hipLaunchKernelGGL(gn_bwd_small_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ldx, (const float*)dy, lddy, coef, mr,
+                       (int)HW, C, C / 32, silu, (const float*)addend, lda, (float*)dx, lddx);
+  prof_end(st);
+  KDIP_LAUNCH_CHECK();
+  return KDIP_OK;
+}
+
 }  // namespace kdip

@@ -252,6 +252,11 @@ int gn_forward(Ctx& c, const void* x, long ldx, int B, long HW, const GnW& g, co
   bool dry = c.dry;
   float* coef = (float*)c.u->persist.alloc(sizeof(float) * B * g.C * 2);
   float* mr = (float*)c.u->persist.alloc(sizeof(float) * B * 64);
+  *coef_out = coef; *mr_out = mr;
+  if (gn_small_eligible(c.dt, HW, g.C)) {
+    RUN(gn_fwd_small(c.st, c.dt, x, ldx, B, HW, g.C, g.gamma, g.beta, film, film_ld, 1e-5f, silu, y, ldy, coef, mr));
+    return KDIP_OK;
+  }
   double* stats = nullptr;
   auto it = c.u->fused_stats.find(x);
   if (it != c.u->fused_stats.end() && ldx == g.C) stats = it->second;        // accumulated by the producing conv
@@ -268,6 +273,10 @@ int gn_forward(Ctx& c, const void* x, long ldx, int B, long HW, const GnW& g, co
 int gn_backward(Ctx& c, const void* x, long ldx, const void* dy, long lddy, const float* coef, const float* mr, int B,
                 long HW, int C, int silu, const void* addend, long lda, void* dx, long lddx, double* fused_sums = nullptr) {
   bool dry = c.dry;
+  if (gn_small_eligible(c.dt, HW, C)) {
+    RUN(gn_bwd_small(c.st, c.dt, x, ldx, dy, lddy, coef, mr, B, HW, C, silu, addend, lda, dx, lddx));
+    return KDIP_OK;
+  }
   double* sums = fused_sums;
   if (!sums) {
     sums = new_sums(c, B);
@@ -281,7 +290,7 @@ int conv_f(Ctx& c, const ConvW& w, const void* x, long ldx, int B, int H, int W,
            long ldr, int out_f32, bool fuse_out_stats = false) {
   bool dry = c.dry;
   ConvStats stt;
-  if (fuse_out_stats && !out_f32 && ldy == w.cout && conv_stats_eligible(H, W, w.cout)) {
+  if (fuse_out_stats && !out_f32 && ldy == w.cout && conv_stats_eligible(H, W, w.cout) && !gn_small_eligible(c.dt, (long)H * W, w.cout)) {
     stt.mode = 1;
     stt.sums = new_sums(c, B);
     c.u->fused_stats[y] = stt.sums;
@@ -299,7 +308,7 @@ int conv_b(Ctx& c, const ConvW& w, const void* g, long ldg, int B, int H, int W,
   bool dry = c.dry;
   ConvStats stt;
   if (sums_out) *sums_out = nullptr;
-  if (gn_x && sums_out && !out_f32 && ldy == w.cin && conv_stats_eligible(H, W, w.cin)) {
+  if (gn_x && sums_out && !out_f32 && ldy == w.cin && conv_stats_eligible(H, W, w.cin) && !gn_small_eligible(c.dt, (long)H * W, w.cin)) {
     stt.mode = 2; stt.silu = gn_silu; stt.x = gn_x; stt.ldx = gn_ldx; stt.coef = gn_coef; stt.mr = gn_mr;
     stt.sums = new_sums(c, B);
     *sums_out = stt.sums;

@@ -78,9 +78,11 @@ def test_conv_dgrad(lib, dtype, case):
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
-@pytest.mark.parametrize("C_,film,silu", [(32, False, True), (64, True, True), (96, True, True), (128, False, False), (384, True, True)])
-def test_groupnorm_fwd_bwd(lib, dtype, C_, film, silu):
-    B, H, W = 2, 16, 16
+@pytest.mark.parametrize("HW_", [16, 48])      # 16x16: one-launch small-map kernels where eligible; 48x48: streaming kernels
+@pytest.mark.parametrize("C_,film,silu", [(32, False, True), (64, True, True), (96, True, True), (128, False, False), (384, True, True),
+                                          (256, True, True), (512, False, True), (1536, True, False)])
+def test_groupnorm_fwd_bwd(lib, dtype, C_, film, silu, HW_):
+    B, H, W = 2, HW_, HW_
     g = torch.Generator().manual_seed(3)
     x = (torch.randn(B, C_, H, W, generator=g) * 1.5 + 0.3).requires_grad_()
     gamma = 1 + 0.1 * torch.randn(C_, generator=g)
