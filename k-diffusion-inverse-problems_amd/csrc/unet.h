@@ -71,7 +71,7 @@ struct UNet {
 
   Arena persist, scratch, zeros;     // zeros: fp64 statistics accumulators, cleared once per forward / VJP
   size_t zeros_fwd_end = 0;
-  std::map<const void*, double*> fused_stats;   // tensor -> GroupNorm sums already accumulated by its producer
+  std::map<std::pair<const void*, int>, double*> fused_stats;   // (tensor, channels) -> GroupNorm sums already accumulated by its producer
   int ws_B = 0;
   bool dry = false;
   // state of the last forward (for the VJP)

@@ -258,8 +258,8 @@ int gn_forward(Ctx& c, const void* x, long ldx, int B, long HW, const GnW& g, co
     return KDIP_OK;
   }
   double* stats = nullptr;
-  auto it = c.u->fused_stats.find(x);
-  if (it != c.u->fused_stats.end() && ldx == g.C) stats = it->second;        // accumulated by the producing conv
+  auto it = c.u->fused_stats.find(std::make_pair(x, g.C));
+  if (it != c.u->fused_stats.end()) stats = it->second;                      // accumulated by the producing conv
   else {
     stats = new_sums(c, B);
     RUN(gn_stats(c.st, c.dt, x, ldx, B, HW, g.C, stats, 1));
@@ -290,10 +290,10 @@ int conv_f(Ctx& c, const ConvW& w, const void* x, long ldx, int B, int H, int W,
            long ldr, int out_f32, bool fuse_out_stats = false) {
   bool dry = c.dry;
   ConvStats stt;
-  if (fuse_out_stats && !out_f32 && ldy == w.cout && conv_stats_eligible(H, W, w.cout) && !gn_small_eligible(c.dt, (long)H * W, w.cout)) {
+  if (fuse_out_stats && !out_f32 && conv_stats_eligible(H, W, w.cout) && !gn_small_eligible(c.dt, (long)H * W, w.cout)) {
     stt.mode = 1;
     stt.sums = new_sums(c, B);
-    c.u->fused_stats[y] = stt.sums;
+    c.u->fused_stats[std::make_pair((const void*)y, w.cout)] = stt.sums;
   }
   RUN(conv_forward(c.st, c.dt, w.ntaps, x, ldx, B, H, W, w.cin_pad, w.wf, w.bias, w.cout, y, ldy, res, ldr, out_f32, 1.f, w.cin,
                    stt.mode ? &stt : nullptr));
@@ -353,7 +353,9 @@ static int upsample2s(hipStream_t st, DType dt, const void* x, long ldx, int B, 
 }
 
 // --------------------------------------------------------------------------- forward ----
-static int res_forward(Ctx& c, Layer& L, const void* x, long ldx, int B, int& H, int& W, const float* film_all, void** outp) {
+// dst/ldd: when given, the block output is written there (a channel slice of a later concat buffer) instead of a fresh tensor
+static int res_forward(Ctx& c, Layer& L, const void* x, long ldx, int B, int& H, int& W, const float* film_all, void** outp,
+                       void* dst = nullptr, long ldd = 0) {
   bool dry = c.dry;
   UNet* u = c.u;
   const size_t es = c.es;
@@ -392,8 +394,8 @@ static int res_forward(Ctx& c, Layer& L, const void* x, long ldx, int B, int& H,
     CK(conv_f(c, L.skip, xs, ldxs, B, Ho, Wo, sk, L.cout, nullptr, 0, 0));
     S = sk; ldS = L.cout;
   }
-  void* o = u->persist.alloc(es * B * HWo * L.cout);
-  CK(conv_f(c, L.c2, h3, L.cout, B, Ho, Wo, o, L.cout, S, ldS, 0, true));
+  void* o = dst ? dst : u->persist.alloc(es * B * HWo * L.cout);
+  CK(conv_f(c, L.c2, h3, L.cout, B, Ho, Wo, o, dst ? ldd : L.cout, S, ldS, 0, true));
   *outp = o; H = Ho; W = Wo;
   return KDIP_OK;
 }
@@ -413,7 +415,8 @@ static void attn_gemms(const Layer& L, int B, int T, int hc, BGemm& qk, BGemm& p
   pv.M = T; pv.N = hc; pv.K = T; pv.nb1 = B; pv.nb2 = heads; pv.alpha = 1.f; pv.c_f32 = 0; pv.a_f32 = 0;
 }
 
-static int attn_forward(Ctx& c, Layer& L, const void* x, long ldx, int B, int H, int W, void** outp) {
+static int attn_forward(Ctx& c, Layer& L, const void* x, long ldx, int B, int H, int W, void** outp, void* dst = nullptr,
+                        long ldd = 0) {
   bool dry = c.dry;
   UNet* u = c.u;
   const size_t es = c.es;
@@ -436,8 +439,8 @@ static int attn_forward(Ctx& c, Layer& L, const void* x, long ldx, int B, int H,
   RUN(bgemm(c.st, c.dt, qk));
   RUN(softmax_rows(c.st, c.dt, S, (long)B * heads * T, T, P));
   RUN(bgemm(c.st, c.dt, pv));
-  void* o = u->persist.alloc(es * (size_t)B * T * C);
-  CK(conv_f(c, L.proj, a, C, B, H, W, o, C, x, ldx, 0, true));
+  void* o = dst ? dst : u->persist.alloc(es * (size_t)B * T * C);
+  CK(conv_f(c, L.proj, a, C, B, H, W, o, dst ? ldd : C, x, ldx, 0, true));
   *outp = o;
   return KDIP_OK;
 }
@@ -465,39 +468,51 @@ int UNet::forward_impl(hipStream_t st, const float* x_nchw, const float* t, int 
   hs_ptr.clear(); hs_C.clear(); cat_ptr.clear();
   std::vector<int> hs_H;
   const void* h = nullptr; long ldh = 0; int Ch = 0;
-  auto run_layers = [&](std::vector<Layer>& ls) -> int {
-    for (auto& L : ls) {
+  // the last layer of a block writes straight into its slice of the concat buffer it feeds (dst/ldd): no
+  // torch.cat copies (guided_diffusion/unet.py:659-662) -- decoder stage j reads cat = [h | hs[nhs-1-j]]
+  auto run_layers = [&](std::vector<Layer>& ls, void* dst, long ldd) -> int {
+    for (size_t li = 0; li < ls.size(); ++li) {
+      Layer& L = ls[li];
+      void* d = li + 1 == ls.size() ? dst : nullptr;
       void* o = nullptr;
       if (L.kind == 0) {
         scratch.reset();
-        o = persist.alloc(es * (size_t)B * H * W * L.cout);
+        o = d ? d : persist.alloc(es * (size_t)B * H * W * L.cout);
         L.sv.B = B; L.sv.H = H; L.sv.W = W;
-        CK(conv_f(c, L.conv, xin, 32, B, H, W, o, L.cout, nullptr, 0, 0, true));
+        CK(conv_f(c, L.conv, xin, 32, B, H, W, o, d ? ldd : L.cout, nullptr, 0, 0, true));
       } else if (L.kind == 1) {
-        CK(res_forward(c, L, h, ldh, B, H, W, film_all, &o));
+        CK(res_forward(c, L, h, ldh, B, H, W, film_all, &o, d, ldd));
       } else {
-        CK(attn_forward(c, L, h, ldh, B, H, W, &o));
+        CK(attn_forward(c, L, h, ldh, B, H, W, &o, d, ldd));
       }
-      h = o; ldh = L.cout; Ch = L.cout;
+      h = o; ldh = d ? ldd : L.cout; Ch = L.cout;
     }
     return KDIP_OK;
   };
-  for (auto& blk : inp) {
-    CK(run_layers(blk));
+  const int nhs = (int)inp.size();
+  KDIP_REQUIRE((int)out.size() == nhs, "internal: %zu decoder stages for %d skips", out.size(), nhs);
+  std::vector<void*> cat(nhs, nullptr);
+  std::vector<long> cat_ld(nhs, 0);
+  std::vector<int> cat_Ch(nhs, 0);                     // channels of the decoder-side half
+  for (int si = 0; si < nhs; ++si) {
+    // resolution / channels of hs[si] = output of encoder block si
+    int Hs = H, Cs = inp[si].back().cout;
+    for (auto& L : inp[si]) if (L.kind == 1 && L.mode == 1) Hs /= 2;
+    const int j = nhs - 1 - si;
+    const int Chf = j == 0 ? mid.back().cout : out[j - 1].back().cout;
+    cat[si] = persist.alloc(es * (size_t)B * Hs * Hs * (Chf + Cs));
+    cat_ld[si] = Chf + Cs; cat_Ch[si] = Chf;
+    CK(run_layers(inp[si], (char*)cat[si] + es * Chf, cat_ld[si]));
+    KDIP_REQUIRE(H == Hs, "internal: skip resolution mismatch");
     hs_ptr.push_back(h); hs_C.push_back(Ch); hs_H.push_back(H);
   }
-  CK(run_layers(mid));
-  int nhs = (int)hs_ptr.size();
-  for (size_t j = 0; j < out.size(); ++j) {
-    int si = nhs - 1 - (int)j;
-    int Cs = hs_C[si];
-    KDIP_REQUIRE(hs_H[si] == H, "internal: skip resolution mismatch");
-    void* cat = persist.alloc(es * (size_t)B * H * W * (Ch + Cs));
-    cat_ptr.push_back(cat);
-    RUN(copy_channels(st, dt, h, ldh, (long)B * H * W, Ch, cat, Ch + Cs));
-    RUN(copy_channels(st, dt, hs_ptr[si], Cs, (long)B * H * W, Cs, (char*)cat + es * Ch, Ch + Cs));
-    h = cat; ldh = Ch + Cs; Ch = Ch + Cs;
-    CK(run_layers(out[j]));
+  CK(run_layers(mid, cat[nhs - 1], cat_ld[nhs - 1]));
+  for (int j = 0; j < nhs; ++j) {
+    const int si = nhs - 1 - j;
+    KDIP_REQUIRE(hs_H[si] == H && Ch == cat_Ch[si], "internal: skip resolution / channel mismatch");
+    cat_ptr.push_back(cat[si]);
+    h = cat[si]; ldh = cat_ld[si]; Ch = (int)cat_ld[si];
+    CK(run_layers(out[j], j + 1 < nhs ? cat[si - 1] : nullptr, j + 1 < nhs ? cat_ld[si - 1] : 0));
   }
   final_h = h;
   // head: GN -> SiLU -> conv3x3 (fp32 out, channels padded to 32)
