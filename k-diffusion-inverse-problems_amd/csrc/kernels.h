@@ -49,14 +49,15 @@ int gn_bwd_stats(hipStream_t st, DType dt, const void* x, long ldx, const void* 
                  const float* mr, int B, long HW, int C, int silu, double* sums, int prezeroed = 0);
 int gn_bwd_apply(hipStream_t st, DType dt, const void* x, long ldx, const void* dy, long lddy, const float* coef,
                  const float* mr, const double* sums, int B, long HW, int C, int silu, const void* addend, long lda,
-                 void* dx, long lddx);
+                 void* dx, long lddx, const void* addend2 = nullptr, long lda2 = 0);
 // small feature maps (HW <= 1024): stats + coefficients + apply in one launch, one block per (image, group)
 bool gn_small_eligible(DType dt, long HW, int C);
 int gn_fwd_small(hipStream_t st, DType dt, const void* x, long ldx, int B, long HW, int C, const float* gamma,
                  const float* beta, const float* film, long film_ld, float eps, int silu, void* y, long ldy, float* coef,
                  float* mr);
 int gn_bwd_small(hipStream_t st, DType dt, const void* x, long ldx, const void* dy, long lddy, const float* coef,
-                 const float* mr, int B, long HW, int C, int silu, const void* addend, long lda, void* dx, long lddx);
+                 const float* mr, int B, long HW, int C, int silu, const void* addend, long lda, void* dx, long lddx,
+                 const void* addend2 = nullptr, long lda2 = 0);
 
 // ---- elementwise.hip --------------------------------------------------------------------
 int avgpool2(hipStream_t st, DType dt, const void* x, long ldx, int B, int H, int W, int C, void* y, long ldy, float scale);

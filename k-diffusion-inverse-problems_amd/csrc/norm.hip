@@ -265,8 +265,8 @@ template <typename T>
 __global__ void gn_bwd_apply_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy, long lddy,
                                     const float* __restrict__ coef, const float* __restrict__ mr,
                                     const double* __restrict__ sums, long HW, int C, int VP, int lanes, int cpg,
-                                    long chunk, int silu, const T* __restrict__ addend, long lda, T* __restrict__ dx,
-                                    long lddx) {
+                                    long chunk, int silu, const T* __restrict__ addend, long lda,
+                                    const T* __restrict__ addend2, long lda2, T* __restrict__ dx, long lddx) {
   constexpr int EPV = TypeInfo<T>::EPV;
   const int tid = threadIdx.x, b = blockIdx.y;
   const int vi = tid % VP, pl = tid / VP;
@@ -288,18 +288,22 @@ __global__ void gn_bwd_apply_kernel(const T* __restrict__ x, long ldx, const T* 
   const T* xb = x + ((long)b * HW) * ldx + (long)vi * EPV;
   const T* db = dy + ((long)b * HW) * lddy + (long)vi * EPV;
   const T* ab = addend ? addend + ((long)b * HW) * lda + (long)vi * EPV : nullptr;
+  const T* ab2 = addend2 ? addend2 + ((long)b * HW) * lda2 + (long)vi * EPV : nullptr;
   T* ob = dx + ((long)b * HW) * lddx + (long)vi * EPV;
   for (long p = p0 + pl; p < p1; p += lanes) {
-    float fx[EPV], fd[EPV], fa[EPV], out[EPV];
+    float fx[EPV], fd[EPV], fa[EPV], fa2[EPV], out[EPV];
     unpack16<T>(*(const uint4*)(xb + p * ldx), fx);
     unpack16<T>(*(const uint4*)(db + p * lddy), fd);
     if (ab) unpack16<T>(*(const uint4*)(ab + p * lda), fa);
+    if (ab2) unpack16<T>(*(const uint4*)(ab2 + p * lda2), fa2);
 #pragma unroll
     for (int e = 0; e < EPV; ++e) {
       float z = ca[e] * fx[e] + cb[e];
       float dz = silu ? fd[e] * silu_grad_f(z) : fd[e];
       float r = ca[e] * dz - (k0[e] + k1[e] * fx[e]);
-      out[e] = ab ? r + fa[e] : r;
+      if (ab) r += fa[e];
+      if (ab2) r += fa2[e];
+      out[e] = r;
     }
     *(uint4*)(ob + p * lddx) = pack16<T>(out);
   }
@@ -307,20 +311,20 @@ __global__ void gn_bwd_apply_kernel(const T* __restrict__ x, long ldx, const T* 
 
 int gn_bwd_apply(hipStream_t st, DType dt, const void* x, long ldx, const void* dy, long lddy, const float* coef,
                  const float* mr, const double* sums, int B, long HW, int C, int silu, const void* addend, long lda,
-                 void* dx, long lddx) {
+                 void* dx, long lddx, const void* addend2, long lda2) {
   long chunk = pick_chunk_stream(HW, B);
   dim3 grid(cdiv(HW, chunk), B);
-  prof_begin(st, PC_GN_BWD_APPLY, 0, (addend ? 4.0 : 3.0) * B * HW * C * (dt == DT_BF16 ? 2.0 : 4.0), "gn", B, HW, C, addend ? 1 : 0);
+  prof_begin(st, PC_GN_BWD_APPLY, 0, (3.0 + (addend ? 1 : 0) + (addend2 ? 1 : 0)) * B * HW * C * (dt == DT_BF16 ? 2.0 : 4.0), "gn", B, HW, C, (addend ? 1 : 0) + (addend2 ? 1 : 0));
   if (dt == DT_BF16) {
     GnGeom g = gn_geom<bf16_t>(C);
     hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, grid, dim3(g.nthreads), 0, st, (const bf16_t*)x, ldx,
                        (const bf16_t*)dy, lddy, coef, mr, sums, HW, C, g.VP, g.lanes, g.cpg, chunk, silu,
-                       (const bf16_t*)addend, lda, (bf16_t*)dx, lddx);
+                       (const bf16_t*)addend, lda, (const bf16_t*)addend2, lda2, (bf16_t*)dx, lddx);
   } else {
     GnGeom g = gn_geom<float>(C);
     hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid, dim3(g.nthreads), 0, st, (const float*)x, ldx,
                        (const float*)dy, lddy, coef, mr, sums, HW, C, g.VP, g.lanes, g.cpg, chunk, silu,
-                       (const float*)addend, lda, (float*)dx, lddx);
+                       (const float*)addend, lda, (const float*)addend2, lda2, (float*)dx, lddx);
   }
   prof_end(st);
   KDIP_LAUNCH_CHECK();
@@ -425,7 +429,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_bwd_small_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy, long lddy,
                                                            const float* __restrict__ coef, const float* __restrict__ mr, int HW,
                                                            int C, int cpg, int silu, const T* __restrict__ addend, long lda,
-                                                           T* __restrict__ dx, long lddx) {
+                                                           const T* __restrict__ addend2, long lda2, T* __restrict__ dx,
+                                                           long lddx) {
   constexpr int EPV = TypeInfo<T>::EPV;
   __shared__ double red[4][2];
   __shared__ float sa[GN_SMALL_MAX_CPG], sb[GN_SMALL_MAX_CPG];
@@ -459,35 +464,40 @@ __global__ __launch_bounds__(256) void gn_bwd_small_kernel(const T* __restrict__
   const float invN = 1.f / ((float)HW * (float)cpg);
   const float k1 = rstd * ((float)d2 * invN), k0 = (float)d1 * invN - mean * k1;
   const T* ab = addend ? addend + (long)b * HW * lda + (long)g * cpg : nullptr;
+  const T* ab2 = addend2 ? addend2 + (long)b * HW * lda2 + (long)g * cpg : nullptr;
   T* ob = dx + (long)b * HW * lddx + (long)g * cpg;
   for (int i = tid; i < nvec; i += 256) {
     const int px = i / vpg, v = i - px * vpg;
-    float fx[EPV], fd[EPV], fa[EPV], out[EPV];
+    float fx[EPV], fd[EPV], fa[EPV], fa2[EPV], out[EPV];
     unpack16<T>(*(const uint4*)(xb + (long)px * ldx + v * EPV), fx);
     unpack16<T>(*(const uint4*)(db + (long)px * lddy + v * EPV), fd);
     if (ab) unpack16<T>(*(const uint4*)(ab + (long)px * lda + v * EPV), fa);
+    if (ab2) unpack16<T>(*(const uint4*)(ab2 + (long)px * lda2 + v * EPV), fa2);
 #pragma unroll
     for (int e = 0; e < EPV; ++e) {
       const float a = sa[v * EPV + e], z = a * fx[e] + sb[v * EPV + e];
       const float dz = silu ? fd[e] * silu_grad_f(z) : fd[e];
-      const float r = a * dz - (k0 + k1 * fx[e]);
-      out[e] = ab ? r + fa[e] : r;
+      float r = a * dz - (k0 + k1 * fx[e]);
+      if (ab) r += fa[e];
+      if (ab2) r += fa2[e];
+      out[e] = r;
     }
     *(uint4*)(ob + (long)px * lddx + v * EPV) = pack16<T>(out);
   }
 }
 
 int gn_bwd_small(hipStream_t st, DType dt, const void* x, long ldx, const void* dy, long lddy, const float* coef,
-                 const float* mr, int B, long HW, int C, int silu, const void* addend, long lda, void* dx, long lddx) {
+                 const float* mr, int B, long HW, int C, int silu, const void* addend, long lda, void* dx, long lddx,
+                 const void* addend2, long lda2) {
   KDIP_REQUIRE(gn_small_eligible(dt, HW, C), "groupnorm(small) backward: unsupported shape HW=%ld C=%d", HW, C);
   dim3 grid(32, B);
-  prof_begin(st, PC_GN_BWD_APPLY, 0, (addend ? 4.0 : 3.0) * B * HW * C * (dt == DT_BF16 ? 2.0 : 4.0), "gn_small", B, HW, C, addend ? 1 : 0);
+  prof_begin(st, PC_GN_BWD_APPLY, 0, (3.0 + (addend ? 1 : 0) + (addend2 ? 1 : 0)) * B * HW * C * (dt == DT_BF16 ? 2.0 : 4.0), "gn_small", B, HW, C, (addend ? 1 : 0) + (addend2 ? 1 : 0));
   if (dt == DT_BF16)
     hipLaunchKernelGGL(gn_bwd_small_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, coef,
-                       mr, (int)HW, C, C / 32, silu, (const bf16_t*)addend, lda, (bf16_t*)dx, lddx);
+                       mr, (int)HW, C, C / 32, silu, (const bf16_t*)addend, lda, (const bf16_t*)addend2, lda2, (bf16_t*)dx, lddx);
   else
     hipLaunchKernelGGL(gn_bwd_small_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ldx, (const float*)dy, lddy, coef, mr,
-                       (int)HW, C, C / 32, silu, (const float*)addend, lda, (float*)dx, lddx);
+                       (int)HW, C, C / 32, silu, (const float*)addend, lda, (const float*)addend2, lda2, (float*)dx, lddx);
   prof_end(st);
   KDIP_LAUNCH_CHECK();
   return KDIP_OK;

@@ -271,10 +271,11 @@ int gn_forward(Ctx& c, const void* x, long ldx, int B, long HW, const GnW& g, co
 }
 
 int gn_backward(Ctx& c, const void* x, long ldx, const void* dy, long lddy, const float* coef, const float* mr, int B,
-                long HW, int C, int silu, const void* addend, long lda, void* dx, long lddx, double* fused_sums = nullptr) {
+                long HW, int C, int silu, const void* addend, long lda, void* dx, long lddx, double* fused_sums = nullptr,
+                const void* addend2 = nullptr, long lda2 = 0) {
   bool dry = c.dry;
   if (gn_small_eligible(c.dt, HW, C)) {
-    RUN(gn_bwd_small(c.st, c.dt, x, ldx, dy, lddy, coef, mr, B, HW, C, silu, addend, lda, dx, lddx));
+    RUN(gn_bwd_small(c.st, c.dt, x, ldx, dy, lddy, coef, mr, B, HW, C, silu, addend, lda, dx, lddx, addend2, lda2));
     return KDIP_OK;
   }
   double* sums = fused_sums;
@@ -282,7 +283,7 @@ int gn_backward(Ctx& c, const void* x, long ldx, const void* dy, long lddy, cons
     sums = new_sums(c, B);
     RUN(gn_bwd_stats(c.st, c.dt, x, ldx, dy, lddy, coef, mr, B, HW, C, silu, sums, 1));
   }
-  RUN(gn_bwd_apply(c.st, c.dt, x, ldx, dy, lddy, coef, mr, sums, B, HW, C, silu, addend, lda, dx, lddx));
+  RUN(gn_bwd_apply(c.st, c.dt, x, ldx, dy, lddy, coef, mr, sums, B, HW, C, silu, addend, lda, dx, lddx, addend2, lda2));
   return KDIP_OK;
 }
 
@@ -535,7 +536,8 @@ int UNet::forward_impl(hipStream_t st, const float* x_nchw, const float* t, int 
 }
 
 // -------------------------------------------------------------------------- backward ----
-static int res_backward(Ctx& c, Layer& L, const void* G, long ldG, void** gxp) {
+// add2/lda2: an extra gradient summed into the result (the concat-skip gradient of the tensor this block consumed)
+static int res_backward(Ctx& c, Layer& L, const void* G, long ldG, void** gxp, const void* add2 = nullptr, long lda2 = 0) {
   bool dry = c.dry;
   UNet* u = c.u;
   const size_t es = c.es;
@@ -580,12 +582,12 @@ static int res_backward(Ctx& c, Layer& L, const void* G, long ldG, void** gxp) {
     g1 = a; gxs = b; ldgxs = L.cin;
   }
   void* gx = u->persist.alloc(es * B * HW * L.cin);
-  CK(gn_backward(c, L.sv.x, L.sv.ldx, g1, L.cin, L.sv.coef1, L.sv.mr1, B, HW, L.cin, 1, gxs, ldgxs, gx, L.cin, sums1));
+  CK(gn_backward(c, L.sv.x, L.sv.ldx, g1, L.cin, L.sv.coef1, L.sv.mr1, B, HW, L.cin, 1, gxs, ldgxs, gx, L.cin, sums1, add2, lda2));
   *gxp = gx;
   return KDIP_OK;
 }
 
-static int attn_backward(Ctx& c, Layer& L, const void* G, long ldG, void** gxp) {
+static int attn_backward(Ctx& c, Layer& L, const void* G, long ldG, void** gxp, const void* add2 = nullptr, long lda2 = 0) {
   bool dry = c.dry;
   UNet* u = c.u;
   const size_t es = c.es;
@@ -628,7 +630,7 @@ static int attn_backward(Ctx& c, Layer& L, const void* G, long ldG, void** gxp) 
   double* sumsn = nullptr;
   CK(conv_b(c, L.qkv, dqkv, 3 * C, B, H, W, gn_in, C, nullptr, 0, 0, L.sv.x, L.sv.ldx, L.sv.coef1, L.sv.mr1, 0, &sumsn));
   void* gx = u->persist.alloc(es * (size_t)B * T * C);
-  CK(gn_backward(c, L.sv.x, L.sv.ldx, gn_in, C, L.sv.coef1, L.sv.mr1, B, T, C, 0, G, ldG, gx, C, sumsn));
+  CK(gn_backward(c, L.sv.x, L.sv.ldx, gn_in, C, L.sv.coef1, L.sv.mr1, B, T, C, 0, G, ldG, gx, C, sumsn, add2, lda2));
   *gxp = gx;
   return KDIP_OK;
 }
@@ -652,12 +654,15 @@ int UNet::vjp_impl(hipStream_t st, const float* cot_nchw, float* gx_nchw) {
   void* G = persist.alloc(es * B * HW0 * final_ch);
   CK(gn_backward(c, final_h, final_ch, ghn, final_ch, out_coef, out_mr, B, HW0, final_ch, 1, nullptr, 0, G, final_ch, sumsh));
   const void* g = G; long ldg = final_ch;
-  auto back_layers = [&](std::vector<Layer>& ls) -> int {
+  // add2: gradient summed into the block's input gradient by its first layer's last kernel (the concat-skip
+  // gradient of the tensor the block consumed) -- replaces a separate add pass per skip connection
+  auto back_layers = [&](std::vector<Layer>& ls, const void* add2 = nullptr, long lda2 = 0) -> int {
     for (int i = (int)ls.size() - 1; i >= 0; --i) {
       Layer& L = ls[i];
       void* gx = nullptr;
-      if (L.kind == 1) CK(res_backward(c, L, g, ldg, &gx));
-      else if (L.kind == 2) CK(attn_backward(c, L, g, ldg, &gx));
+      const void* a2 = i == 0 ? add2 : nullptr;
+      if (L.kind == 1) CK(res_backward(c, L, g, ldg, &gx, a2, lda2));
+      else if (L.kind == 2) CK(attn_backward(c, L, g, ldg, &gx, a2, lda2));
       else return set_error(KDIP_ERR_STATE, "internal: conv layer inside block list");
       g = gx; ldg = L.cin;
     }
@@ -677,27 +682,16 @@ int UNet::vjp_impl(hipStream_t st, const float* cot_nchw, float* gx_nchw) {
     skip_ld[si] = Ctot;
     // g (first Chh channels, ld = Ctot) continues
   }
-  CK(back_layers(mid));
-  for (int i = nhs - 1; i >= 1; --i) {
-    // grad wrt hs[i] = g (from the consumer chain) + skip grad
-    Layer& Llast = inp[i].back();
-    const int Cc = Llast.cout;
-    const int Hh = Llast.kind == 1 ? (Llast.mode == 1 ? Llast.sv.H / 2 : (Llast.mode == 2 ? Llast.sv.H * 2 : Llast.sv.H)) : Llast.sv.H;
-    const long np = (long)B * Hh * Hh;
-    void* sum = persist.alloc(es * np * Cc);
-    RUN(add_channels(st, dt, g, ldg, skip_g[i], skip_ld[i], np, Cc, sum, Cc));
-    g = sum; ldg = Cc;
-    CK(back_layers(inp[i]));
-  }
-  // input_blocks.0: conv3x3(3->ch). grad wrt hs[0] = g + skip grad; dgrad to the 3 input channels (fp32)
+  // grad wrt hs[i] = chain gradient + concat-skip gradient: the skip part rides along as add2
+  CK(back_layers(mid, skip_g[nhs - 1], skip_ld[nhs - 1]));
+  for (int i = nhs - 1; i >= 1; --i) CK(back_layers(inp[i], skip_g[i - 1], skip_ld[i - 1]));
+  // input_blocks.0: conv3x3(3->ch); g is the complete gradient wrt hs[0]: dgrad to the 3 input channels (fp32)
   {
     Layer& L0 = inp[0][0];
     const long np = (long)B * HW0;
-    void* sum = persist.alloc(es * np * L0.cout);
-    RUN(add_channels(st, dt, g, ldg, skip_g[0], skip_ld[0], np, L0.cout, sum, L0.cout));
     scratch.reset();
     float* gx32 = (float*)scratch.alloc(sizeof(float) * np * 32);
-    CK(conv_b(c, L0.conv, sum, L0.cout, B, H0, W0, gx32, 32, nullptr, 0, 1));
+    CK(conv_b(c, L0.conv, g, ldg, B, H0, W0, gx32, 32, nullptr, 0, 1));
     RUN(nhwc_to_nchw_f32(st, gx32, 32, B, cfg.in_channels, H0, W0, gx_nchw));
   }
   return KDIP_OK;
