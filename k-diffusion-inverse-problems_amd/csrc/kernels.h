@@ -46,10 +46,15 @@ int gn_apply(hipStream_t st, DType dt, const void* x, long ldx, const float* coe
              void* y, long ldy);
 // backward: dy wrt apply output -> dx (+ optional addend), two passes.
 int gn_bwd_stats(hipStream_t st, DType dt, const void* x, long ldx, const void* dy, long lddy, const float* coef,
-                 const float* mr, int B, long HW, int C, int silu, double* sums, int prezeroed = 0);
+                 const float* mr, int B, long HW, int C, int silu, double* sums, int prezeroed = 0, int half_lgW = -1);
 int gn_bwd_apply(hipStream_t st, DType dt, const void* x, long ldx, const void* dy, long lddy, const float* coef,
                  const float* mr, const double* sums, int B, long HW, int C, int silu, const void* addend, long lda,
-                 void* dx, long lddx, const void* addend2 = nullptr, long lda2 = 0);
+                 void* dx, long lddx, const void* addend2 = nullptr, long lda2 = 0, int half_lgW = -1);
+// half_lgW >= 0 (W = 1 << half_lgW): dy / addend are HALF-resolution tensors standing for 0.25 * nearest-upsample (the adjoint
+// of the 2x2 average pool of a downsampling ResBlock), read in place instead of being materialised at full resolution.
+// GN apply (+SiLU) fused with the 2x2 average pool of both the activated tensor (yp) and the raw input (xp)
+int gn_apply_pool2(hipStream_t st, DType dt, const void* x, long ldx, const float* coef, int B, int H, int W, int C, int silu,
+                   void* yp, long ldy, void* xp, long ldxp);
 // small feature maps (HW <= 1024): stats + coefficients + apply in one launch, one block per (image, group)
 bool gn_small_eligible(DType dt, long HW, int C);
 int gn_fwd_small(hipStream_t st, DType dt, const void* x, long ldx, int B, long HW, int C, const float* gamma,

@@ -190,13 +190,73 @@ int gn_apply(hipStream_t st, DType dt, const void* x, long ldx, const float* coe
   return KDIP_OK;
 }
 
+// Downsampling ResBlocks (guided_diffusion/unet.py:236-240: h = avg_pool(SiLU(GN(x))), x = avg_pool(x)):
+// one pass over x produces both pooled tensors (instead of apply + two pool kernels = 4.5 tensor passes).
+template <typename T>
+__global__ void gn_apply_pool2_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ coef, int B, int H, int W,
+                                      int C, int VP, int silu, T* __restrict__ yp, long ldy, T* __restrict__ xp, long ldxp) {
+  constexpr int EPV = TypeInfo<T>::EPV;
+  const int Ho = H / 2, Wo = W / 2;
+  const long nvec = (long)B * Ho * Wo * VP;
+  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (long)gridDim.x * blockDim.x) {
+    const int vi = (int)(v % VP);
+    const long op = v / VP;
+    const int ox = (int)(op % Wo);
+    const long t = op / Wo;
+    const int oy = (int)(t % Ho), b = (int)(t / Ho);
+    const T* p = x + (((long)b * H + 2 * oy) * W + 2 * ox) * ldx + (long)vi * EPV;
+    float ca[EPV], cb[EPV], sy[EPV], sx[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+      ca[e] = coef[((long)b * C + vi * EPV + e) * 2];
+      cb[e] = coef[((long)b * C + vi * EPV + e) * 2 + 1];
+      sy[e] = 0.f; sx[e] = 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float f[EPV];
+      unpack16<T>(*(const uint4*)(p + (long)(q >> 1) * W * ldx + (long)(q & 1) * ldx), f);
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) {
+        const float z = ca[e] * f[e] + cb[e];
+        sy[e] += silu ? silu_f(z) : z;
+        sx[e] += f[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) { sy[e] *= 0.25f; sx[e] *= 0.25f; }
+    *(uint4*)(yp + op * ldy + (long)vi * EPV) = pack16<T>(sy);
+    *(uint4*)(xp + op * ldxp + (long)vi * EPV) = pack16<T>(sx);
+  }
+}
+
+int gn_apply_pool2(hipStream_t st, DType dt, const void* x, long ldx, const float* coef, int B, int H, int W, int C, int silu,
+                   void* yp, long ldy, void* xp, long ldxp) {
+  const int VP = C / (dt == DT_BF16 ? 8 : 4);
+  const long nvec = (long)B * (H / 2) * (W / 2) * VP;
+  long g = (nvec + 255) / 256; if (g > 16384) g = 16384; if (g < 1) g = 1;
+  prof_begin(st, PC_GN_APPLY, 0, 1.5 * B * H * W * C * (dt == DT_BF16 ? 2.0 : 4.0), "gn_pool", B, (long)H * W, C, 0);
+  if (dt == DT_BF16)
+    hipLaunchKernelGGL(gn_apply_pool2_kernel<bf16_t>, dim3((unsigned)g), dim3(256), 0, st, (const bf16_t*)x, ldx, coef, B, H, W, C,
+                       VP, silu, (bf16_t*)yp, ldy, (bf16_t*)xp, ldxp);
+  else
+    hipLaunchKernelGGL(gn_apply_pool2_kernel<float>, dim3((unsigned)g), dim3(256), 0, st, (const float*)x, ldx, coef, B, H, W, C, VP,
+                       silu, (float*)yp, ldy, (float*)xp, ldxp);
+  prof_end(st);
+  KDIP_LAUNCH_CHECK();
+  return KDIP_OK;
+}
+
 // --------------------------------------------------------------------------- backward ----
 // z = a*x + b, y = silu(z) | z.  dz = dy*silu'(z) | dy.  xh = (x-mean)*rstd.
 // T1 = sum_g a*dz, T2 = sum_g a*dz*xh;   dx = a*dz - T1/N - xh*T2/N   (N = HW*cpg)
 template <typename T>
 __global__ void gn_bwd_stats_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy, long lddy,
                                     const float* __restrict__ coef, const float* __restrict__ mr, long HW, int C,
-                                    int VP, int lanes, int cpg, long chunk, int silu, double* __restrict__ sums) {
+                                    int VP, int lanes, int cpg, long chunk, int silu, double* __restrict__ sums,
+                                    int half_lgW) {
+  // half_lgW >= 0: dy is a half-resolution tensor (adjoint of the 2x2 average pool, unet.py:236-240 backward):
+  // dy(p) = 0.25 * dy_half[(y >> 1, x >> 1)], W = 1 << half_lgW, dy batch stride HW / 4
   constexpr int EPV = TypeInfo<T>::EPV;
   __shared__ double sh[32][2];
   const int tid = threadIdx.x, b = blockIdx.y;
@@ -216,15 +276,17 @@ __global__ void gn_bwd_stats_kernel(const T* __restrict__ x, long ldx, const T* 
     }
     long p0 = (long)blockIdx.x * chunk, p1 = p0 + chunk < HW ? p0 + chunk : HW;
     const T* xb = x + ((long)b * HW) * ldx + (long)vi * EPV;
-    const T* db = dy + ((long)b * HW) * lddy + (long)vi * EPV;
+    const T* db = dy + ((long)b * (half_lgW >= 0 ? HW >> 2 : HW)) * lddy + (long)vi * EPV;
+    const float dscale = half_lgW >= 0 ? 0.25f : 1.f;
     for (long p = p0 + pl; p < p1; p += lanes) {
       float fx[EPV], fd[EPV];
       unpack16<T>(*(const uint4*)(xb + p * ldx), fx);
-      unpack16<T>(*(const uint4*)(db + p * lddy), fd);
+      const long pd = half_lgW >= 0 ? (((p >> half_lgW) >> 1) << (half_lgW - 1)) + ((p & ((1L << half_lgW) - 1)) >> 1) : p;
+      unpack16<T>(*(const uint4*)(db + pd * lddy), fd);
 #pragma unroll
       for (int e = 0; e < EPV; ++e) {
         float z = a[e] * fx[e] + bb[e];
-        float dz = silu ? fd[e] * silu_grad_f(z) : fd[e];
+        float dz = (silu ? fd[e] * silu_grad_f(z) : fd[e]) * dscale;
         float adz = a[e] * dz;
         t1[e] += adz;
         t2[e] += adz * (fx[e] - mean[e]) * rstd[e];
@@ -242,7 +304,7 @@ __global__ void gn_bwd_stats_kernel(const T* __restrict__ x, long ldx, const T* 
 }
 
 int gn_bwd_stats(hipStream_t st, DType dt, const void* x, long ldx, const void* dy, long lddy, const float* coef,
-                 const float* mr, int B, long HW, int C, int silu, double* sums, int prezeroed) {
+                 const float* mr, int B, long HW, int C, int silu, double* sums, int prezeroed, int half_lgW) {
   if (!prezeroed) KDIP_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * B * 64, st));
   long chunk = pick_chunk(HW, B);
   dim3 grid(cdiv(HW, chunk), B);
@@ -250,11 +312,11 @@ int gn_bwd_stats(hipStream_t st, DType dt, const void* x, long ldx, const void* 
   if (dt == DT_BF16) {
     GnGeom g = gn_geom<bf16_t>(C);
     hipLaunchKernelGGL(gn_bwd_stats_kernel<bf16_t>, grid, dim3(g.nthreads), 0, st, (const bf16_t*)x, ldx,
-                       (const bf16_t*)dy, lddy, coef, mr, HW, C, g.VP, g.lanes, g.cpg, chunk, silu, sums);
+                       (const bf16_t*)dy, lddy, coef, mr, HW, C, g.VP, g.lanes, g.cpg, chunk, silu, sums, half_lgW);
   } else {
     GnGeom g = gn_geom<float>(C);
     hipLaunchKernelGGL(gn_bwd_stats_kernel<float>, grid, dim3(g.nthreads), 0, st, (const float*)x, ldx,
-                       (const float*)dy, lddy, coef, mr, HW, C, g.VP, g.lanes, g.cpg, chunk, silu, sums);
+                       (const float*)dy, lddy, coef, mr, HW, C, g.VP, g.lanes, g.cpg, chunk, silu, sums, half_lgW);
   }
   prof_end(st);
   KDIP_LAUNCH_CHECK();
@@ -266,7 +328,8 @@ __global__ void gn_bwd_apply_kernel(const T* __restrict__ x, long ldx, const T* 
                                     const float* __restrict__ coef, const float* __restrict__ mr,
                                     const double* __restrict__ sums, long HW, int C, int VP, int lanes, int cpg,
                                     long chunk, int silu, const T* __restrict__ addend, long lda,
-                                    const T* __restrict__ addend2, long lda2, T* __restrict__ dx, long lddx) {
+                                    const T* __restrict__ addend2, long lda2, T* __restrict__ dx, long lddx, int half_lgW) {
+  // half_lgW >= 0: dy and addend are half-resolution tensors (see gn_bwd_stats_kernel); addend2 stays full resolution
   constexpr int EPV = TypeInfo<T>::EPV;
   const int tid = threadIdx.x, b = blockIdx.y;
   const int vi = tid % VP, pl = tid / VP;
@@ -286,22 +349,25 @@ __global__ void gn_bwd_apply_kernel(const T* __restrict__ x, long ldx, const T* 
   }
   long p0 = (long)blockIdx.x * chunk, p1 = p0 + chunk < HW ? p0 + chunk : HW;
   const T* xb = x + ((long)b * HW) * ldx + (long)vi * EPV;
-  const T* db = dy + ((long)b * HW) * lddy + (long)vi * EPV;
-  const T* ab = addend ? addend + ((long)b * HW) * lda + (long)vi * EPV : nullptr;
+  const long HWd = half_lgW >= 0 ? HW >> 2 : HW;
+  const float dscale = half_lgW >= 0 ? 0.25f : 1.f;
+  const T* db = dy + ((long)b * HWd) * lddy + (long)vi * EPV;
+  const T* ab = addend ? addend + ((long)b * HWd) * lda + (long)vi * EPV : nullptr;
   const T* ab2 = addend2 ? addend2 + ((long)b * HW) * lda2 + (long)vi * EPV : nullptr;
   T* ob = dx + ((long)b * HW) * lddx + (long)vi * EPV;
   for (long p = p0 + pl; p < p1; p += lanes) {
     float fx[EPV], fd[EPV], fa[EPV], fa2[EPV], out[EPV];
     unpack16<T>(*(const uint4*)(xb + p * ldx), fx);
-    unpack16<T>(*(const uint4*)(db + p * lddy), fd);
-    if (ab) unpack16<T>(*(const uint4*)(ab + p * lda), fa);
+    const long pd = half_lgW >= 0 ? (((p >> half_lgW) >> 1) << (half_lgW - 1)) + ((p & ((1L << half_lgW) - 1)) >> 1) : p;
+    unpack16<T>(*(const uint4*)(db + pd * lddy), fd);
+    if (ab) unpack16<T>(*(const uint4*)(ab + pd * lda), fa);
     if (ab2) unpack16<T>(*(const uint4*)(ab2 + p * lda2), fa2);
 #pragma unroll
     for (int e = 0; e < EPV; ++e) {
       float z = ca[e] * fx[e] + cb[e];
-      float dz = silu ? fd[e] * silu_grad_f(z) : fd[e];
+      float dz = (silu ? fd[e] * silu_grad_f(z) : fd[e]) * dscale;
       float r = ca[e] * dz - (k0[e] + k1[e] * fx[e]);
-      if (ab) r += fa[e];
+      if (ab) r += fa[e] * dscale;
       if (ab2) r += fa2[e];
       out[e] = r;
     }
@@ -311,7 +377,7 @@ __global__ void gn_bwd_apply_kernel(const T* __restrict__ x, long ldx, const T* 
 
 int gn_bwd_apply(hipStream_t st, DType dt, const void* x, long ldx, const void* dy, long lddy, const float* coef,
                  const float* mr, const double* sums, int B, long HW, int C, int silu, const void* addend, long lda,
-                 void* dx, long lddx, const void* addend2, long lda2) {
+                 void* dx, long lddx, const void* addend2, long lda2, int half_lgW) {
   long chunk = pick_chunk_stream(HW, B);
   dim3 grid(cdiv(HW, chunk), B);
   prof_begin(st, PC_GN_BWD_APPLY, 0, (3.0 + (addend ? 1 : 0) + (addend2 ? 1 : 0)) * B * HW * C * (dt == DT_BF16 ? 2.0 : 4.0), "gn", B, HW, C, (addend ? 1 : 0) + (addend2 ? 1 : 0));
@@ -319,12 +385,12 @@ int gn_bwd_apply(hipStream_t st, DType dt, const void* x, long ldx, const void* 
     GnGeom g = gn_geom<bf16_t>(C);
     hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, grid, dim3(g.nthreads), 0, st, (const bf16_t*)x, ldx,
                        (const bf16_t*)dy, lddy, coef, mr, sums, HW, C, g.VP, g.lanes, g.cpg, chunk, silu,
-                       (const bf16_t*)addend, lda, (const bf16_t*)addend2, lda2, (bf16_t*)dx, lddx);
+                       (const bf16_t*)addend, lda, (const bf16_t*)addend2, lda2, (bf16_t*)dx, lddx, half_lgW);
   } else {
     GnGeom g = gn_geom<float>(C);
     hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid, dim3(g.nthreads), 0, st, (const float*)x, ldx,
                        (const float*)dy, lddy, coef, mr, sums, HW, C, g.VP, g.lanes, g.cpg, chunk, silu,
-                       (const float*)addend, lda, (const float*)addend2, lda2, (float*)dx, lddx);
+                       (const float*)addend, lda, (const float*)addend2, lda2, (float*)dx, lddx, half_lgW);
   }
   prof_end(st);
   KDIP_LAUNCH_CHECK();

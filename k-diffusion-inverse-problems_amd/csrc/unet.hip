@@ -247,8 +247,9 @@ struct Ctx {
 
 double* new_sums(Ctx& c, int B) { return (double*)c.u->zeros.alloc(sizeof(double) * B * 64); }
 
+// pool_W > 0: y / pool_x receive the 2x2-average-pooled activated / raw tensors instead (downsampling ResBlock)
 int gn_forward(Ctx& c, const void* x, long ldx, int B, long HW, const GnW& g, const float* film, int silu, void* y,
-               long ldy, float** coef_out, float** mr_out, long film_ld = 0) {
+               long ldy, float** coef_out, float** mr_out, long film_ld = 0, int pool_W = 0, void* pool_x = nullptr) {
   bool dry = c.dry;
   float* coef = (float*)c.u->persist.alloc(sizeof(float) * B * g.C * 2);
   float* mr = (float*)c.u->persist.alloc(sizeof(float) * B * 64);
@@ -265,25 +266,26 @@ int gn_forward(Ctx& c, const void* x, long ldx, int B, long HW, const GnW& g, co
     RUN(gn_stats(c.st, c.dt, x, ldx, B, HW, g.C, stats, 1));
   }
   RUN(gn_coef(c.st, stats, g.gamma, g.beta, film, B, HW, g.C, 1e-5f, coef, mr, film_ld));
-  RUN(gn_apply(c.st, c.dt, x, ldx, coef, B, HW, g.C, silu, y, ldy));
+  if (pool_W > 0) RUN(gn_apply_pool2(c.st, c.dt, x, ldx, coef, B, (int)(HW / pool_W), pool_W, g.C, silu, y, ldy, pool_x, g.C));
+  else RUN(gn_apply(c.st, c.dt, x, ldx, coef, B, HW, g.C, silu, y, ldy));
   *coef_out = coef; *mr_out = mr;
   return KDIP_OK;
 }
 
 int gn_backward(Ctx& c, const void* x, long ldx, const void* dy, long lddy, const float* coef, const float* mr, int B,
                 long HW, int C, int silu, const void* addend, long lda, void* dx, long lddx, double* fused_sums = nullptr,
-                const void* addend2 = nullptr, long lda2 = 0) {
+                const void* addend2 = nullptr, long lda2 = 0, int half_lgW = -1) {
   bool dry = c.dry;
-  if (gn_small_eligible(c.dt, HW, C)) {
+  if (half_lgW < 0 && gn_small_eligible(c.dt, HW, C)) {
     RUN(gn_bwd_small(c.st, c.dt, x, ldx, dy, lddy, coef, mr, B, HW, C, silu, addend, lda, dx, lddx, addend2, lda2));
     return KDIP_OK;
   }
   double* sums = fused_sums;
   if (!sums) {
     sums = new_sums(c, B);
-    RUN(gn_bwd_stats(c.st, c.dt, x, ldx, dy, lddy, coef, mr, B, HW, C, silu, sums, 1));
+    RUN(gn_bwd_stats(c.st, c.dt, x, ldx, dy, lddy, coef, mr, B, HW, C, silu, sums, 1, half_lgW));
   }
-  RUN(gn_bwd_apply(c.st, c.dt, x, ldx, dy, lddy, coef, mr, sums, B, HW, C, silu, addend, lda, dx, lddx, addend2, lda2));
+  RUN(gn_bwd_apply(c.st, c.dt, x, ldx, dy, lddy, coef, mr, sums, B, HW, C, silu, addend, lda, dx, lddx, addend2, lda2, half_lgW));
   return KDIP_OK;
 }
 
@@ -363,16 +365,21 @@ static int res_forward(Ctx& c, Layer& L, const void* x, long ldx, int B, int& H,
   u->scratch.reset();
   L.sv.x = x; L.sv.ldx = ldx; L.sv.B = B; L.sv.H = H; L.sv.W = W;
   const long HW = (long)H * W;
-  void* h1 = u->scratch.alloc(es * B * HW * L.cin);
-  CK(gn_forward(c, x, ldx, B, HW, L.n1, nullptr, 1, h1, L.cin, &L.sv.coef1, &L.sv.mr1));
+  const bool fused_pool = L.mode == 1 && !gn_small_eligible(c.dt, HW, L.cin);   // GN + SiLU + both 2x2 pools in one pass over x
+  void* h1 = fused_pool ? nullptr : u->scratch.alloc(es * B * HW * L.cin);
+  if (!fused_pool) CK(gn_forward(c, x, ldx, B, HW, L.n1, nullptr, 1, h1, L.cin, &L.sv.coef1, &L.sv.mr1));
   const void* cin_ptr = h1; const void* xs = x; long ldxs = ldx;
   int Ho = H, Wo = W;
   if (L.mode == 1) {
     Ho = H / 2; Wo = W / 2;
     void* h1p = u->scratch.alloc(es * B * Ho * Wo * L.cin);
     void* xp = u->scratch.alloc(es * B * Ho * Wo * L.cin);
-    RUN(avgpool2(c.st, c.dt, h1, L.cin, B, H, W, L.cin, h1p, L.cin, 0.25f));
-    RUN(avgpool2(c.st, c.dt, x, ldx, B, H, W, L.cin, xp, L.cin, 0.25f));
+    if (fused_pool) {
+      CK(gn_forward(c, x, ldx, B, HW, L.n1, nullptr, 1, h1p, L.cin, &L.sv.coef1, &L.sv.mr1, 0, W, xp));
+    } else {
+      RUN(avgpool2(c.st, c.dt, h1, L.cin, B, H, W, L.cin, h1p, L.cin, 0.25f));
+      RUN(avgpool2(c.st, c.dt, x, ldx, B, H, W, L.cin, xp, L.cin, 0.25f));
+    }
     cin_ptr = h1p; xs = xp; ldxs = L.cin;
   } else if (L.mode == 2) {
     Ho = H * 2; Wo = W * 2;
@@ -568,7 +575,10 @@ static int res_backward(Ctx& c, Layer& L, const void* G, long ldG, void** gxp, c
     gS = t; ldgS = L.cin;
   }
   const void* g1 = g1p; const void* gxs = gS; long ldgxs = ldgS;
-  if (L.mode == 1) {        // adjoint of 2x2 average pool: nearest upsample * 1/4
+  int half_lgW = -1;
+  if (L.mode == 1 && !gn_small_eligible(c.dt, HW, L.cin) && (W & (W - 1)) == 0 && W >= 2) {
+    half_lgW = __builtin_ctz(W);   // the GroupNorm-backward kernels read the half-resolution gradients in place (x 1/4)
+  } else if (L.mode == 1) {        // adjoint of 2x2 average pool: nearest upsample * 1/4
     void* a = u->scratch.alloc(es * B * HW * L.cin);
     void* b = u->scratch.alloc(es * B * HW * L.cin);
     RUN(upsample2s(c.st, c.dt, g1p, L.cin, B, Ho, Wo, L.cin, a, L.cin, 0.25f));
@@ -582,7 +592,7 @@ static int res_backward(Ctx& c, Layer& L, const void* G, long ldG, void** gxp, c
     g1 = a; gxs = b; ldgxs = L.cin;
   }
   void* gx = u->persist.alloc(es * B * HW * L.cin);
-  CK(gn_backward(c, L.sv.x, L.sv.ldx, g1, L.cin, L.sv.coef1, L.sv.mr1, B, HW, L.cin, 1, gxs, ldgxs, gx, L.cin, sums1, add2, lda2));
+  CK(gn_backward(c, L.sv.x, L.sv.ldx, g1, L.cin, L.sv.coef1, L.sv.mr1, B, HW, L.cin, 1, gxs, ldgxs, gx, L.cin, sums1, add2, lda2, half_lgW));
   *gxp = gx;
   return KDIP_OK;
 }
