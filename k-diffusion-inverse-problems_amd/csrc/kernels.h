@@ -55,7 +55,7 @@ int gn_bwd_apply(hipStream_t st, DType dt, const void* x, long ldx, const void* 
 // GN apply (+SiLU) fused with the 2x2 average pool of both the activated tensor (yp) and the raw input (xp)
 int gn_apply_pool2(hipStream_t st, DType dt, const void* x, long ldx, const float* coef, int B, int H, int W, int C, int silu,
                    void* yp, long ldy, void* xp, long ldxp);
-// small feature maps (HW <= 1024): stats + coefficients + apply in one launch, one block per (image, group)
+// small feature maps (HW <= 256): stats + coefficients + apply in one launch, one block per (image, group)
 bool gn_small_eligible(DType dt, long HW, int C);
 int gn_fwd_small(hipStream_t st, DType dt, const void* x, long ldx, int B, long HW, int C, const float* gamma,
                  const float* beta, const float* film, long film_ld, float eps, int silu, void* y, long ldy, float* coef,

@@ -398,11 +398,15 @@ int gn_bwd_apply(hipStream_t st, DType dt, const void* x, long ldx, const void* 
 }
 
 // ------------------------------------------------------------- small feature maps ----
-// HW <= 1024 (the 8x8 ... 32x32 levels): the whole (image, group) slab is a few KB, so the
+// HW <= 256 (the 8x8 and 16x16 levels): the whole (image, group) slab is a few KB, so the
 // stats / coef / apply chain (3 launches forward, 2 backward, each launch-latency bound at
 // 10-40 us) collapses into one block per (image, group) that reads its slab twice (second
 // read from L1/L2).  Same arithmetic as the streaming kernels above.
 constexpr int GN_SMALL_MAX_CPG = 128;
+#ifndef KDIP_GN_SMALL_HW
+#define KDIP_GN_SMALL_HW 256
+#endif
+constexpr long GN_SMALL_MAX_HW = KDIP_GN_SMALL_HW;   // 32x32 maps (HW = 1024) measured faster on the streaming kernels + conv-fused statistics
 
 __device__ inline void block_sum2_d(double& a, double& b, double (*red)[2]) {
   a = wave_sum_d(a); b = wave_sum_d(b);
@@ -471,7 +475,7 @@ __global__ __launch_bounds__(256) void gn_fwd_small_kernel(const T* __restrict__
 
 bool gn_small_eligible(DType dt, long HW, int C) {
   const int cpg = C / 32, epv = dt == DT_BF16 ? 8 : 4;
-  return HW <= 1024 && C % 32 == 0 && cpg % epv == 0 && cpg <= GN_SMALL_MAX_CPG;
+  return HW <= GN_SMALL_MAX_HW && C % 32 == 0 && cpg % epv == 0 && cpg <= GN_SMALL_MAX_CPG;
 }
 
 int gn_fwd_small(hipStream_t st, DType dt, const void* x, long ldx, int B, long HW, int C, const float* gamma,

@@ -36,23 +36,35 @@ static inline int pad32(int c) { return (c + 31) / 32 * 32; }
 __global__ void linear_f32_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                   const float* __restrict__ bias, int B, int in, int out, int silu_in,
                                   float* __restrict__ y) {
-  long o = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  int lane = threadIdx.x & 63;
-  if (o >= (long)B * out) return;
-  int b = (int)(o / out), oc = (int)(o % out);
-  const float* xr = x + (long)b * in;
+  // one wave per output feature, all batch rows (8 at a time): the weight row is streamed once instead of B times
+  const int oc = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (oc >= out) return;
   const float* wr = w + (long)oc * in;
-  float s = 0.f;
-  for (int i = lane; i < in; i += 64) {
-    float xv = xr[i];
-    if (silu_in) xv = xv / (1.f + expf(-xv));
-    s += xv * wr[i];
+  const float bv = bias[oc];
+  for (int b0 = 0; b0 < B; b0 += 8) {
+    float s[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = 0.f;
+    for (int i = lane; i < in; i += 64) {
+      const float wv = wr[i];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (b0 + j < B) {
+          float xv = x[(long)(b0 + j) * in + i];
+          if (silu_in) xv = xv / (1.f + expf(-xv));
+          s[j] += xv * wv;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float t = wave_sum(s[j]);
+      if (lane == 0 && b0 + j < B) y[(long)(b0 + j) * out + oc] = t + bv;
+    }
   }
-  s = wave_sum(s);
-  if (lane == 0) y[o] = s + bias[oc];
 }
 static int linear_f32(hipStream_t st, const float* x, const LinW& L, int B, int silu_in, float* y) {
-  hipLaunchKernelGGL(linear_f32_kernel, dim3(cdiv((long)B * L.out, 4)), dim3(256), 0, st, x, L.w, L.b, B, L.in, L.out,
+  hipLaunchKernelGGL(linear_f32_kernel, dim3(cdiv((long)L.out, 4)), dim3(256), 0, st, x, L.w, L.b, B, L.in, L.out,
                      silu_in, y);
   KDIP_LAUNCH_CHECK();
   return KDIP_OK;

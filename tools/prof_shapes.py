@@ -23,7 +23,7 @@ dump = os.path.join(tempfile.gettempdir(), "kdip_shapes.csv")
 L.check(lib.kdip_profile_dump(dump.encode())); L.check(lib.kdip_profile_enable(0))
 grp = collections.defaultdict(lambda: [0, 0.0, 0.0, 0.0])
 for r in csv.DictReader(open(dump)):
-    k = (r["class"], r["d0"], r["d1"], r["d2"], r["d3"])
+    k = (r["class"] + ("/small" if r["tag"] == "gn_small" else "/pool" if r["tag"] == "gn_pool" else ""), r["d0"], r["d1"], r["d2"], r["d3"])
     g = grp[k]; g[0] += 1; g[1] += float(r["us"]); g[2] += float(r["gflop"]); g[3] += float(r["mbytes"])
 tot = sum(g[1] for g in grp.values())
 print(f"profiled total {tot/1e3:.2f} ms (one Heun step = 2 guided calls)")
