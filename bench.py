@@ -1,16 +1,16 @@
 #!/usr/bin/env python
 """Benchmark of the hot path: BASELINE.json configs[1] -- FFHQ 256x256 Gaussian deblur, Type-I
-guidance with Convert posterior covariance, 100 Heun steps, batch 16 per MI355X.
+guidance with Convert posterior covariance, 100 Heun steps, batch 64 per MI355X (--batch).
 
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one Heun sampler step of the 100-step Karras schedule over one batch of 16 synthetic
+A "step" is one Heun sampler step of the 100-step Karras schedule over one batch of 64 synthetic
 images (2 guided-denoiser calls = 2 UNet forwards + 2 hand-written UNet VJPs + 2 mat-solves, CG
 on the sigma < 0.2 steps).  With K = 100 (default) the timed region is the whole sampler run; with
 K < 100 the K timed steps are spread evenly over the schedule (so the closed-form / CG mix is
 preserved) and each starts from x0 + sigma_i * noise.  Inputs are resident in HBM before the
-timed region.  value = images/s of the whole job = N * 16 / (100 * seconds_per_step).
+timed region.  value = images/s of the whole job = N * batch / (100 * seconds_per_step).
 
 Extra objects on the JSON line:
   roofline     dominant kernel (bf16 3x3 implicit-GEMM conv): algorithmic FLOPs / HIP-event time,
@@ -105,7 +105,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=16, help="images per GPU")
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -174,7 +174,7 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic (seeded smooth images, random-init FFHQ-architecture weights)",
         "config": {"workload": "BASELINE configs[1]: FFHQ 256x256 Gaussian deblur (61x61 PSF, sigma_s=0.05), Type-I guidance, "
-                               "Convert covariance (CG below sigma 0.2), 100 Heun steps (--ode), batch 16 per GPU",
+                               "Convert covariance (CG below sigma 0.2), 100 Heun steps (--ode), batch " + str(B) + " per GPU",
                    "global_batch": env.world_size * B, "per_gpu_batch": B, "calls_per_image": CALLS_PER_IMAGE,
                    "timed_steps": "full 100-step sampler run" if full_run else "evenly spaced subset of the 100-step schedule",
                    "parallelism": f"dp{env.world_size} (independent images, one all_gather at the end)"},

@@ -158,7 +158,8 @@ int kdip_profile_dump(const char* path);
 /* ------------------------------------------------------------------ low-level test hooks
  * (exercised by tests/ to localise kernel bugs; NHWC tensors of the UNet storage dtype) */
 int kdip_test_conv(void* stream, int dtype, int ntaps, const float* x_nchw_dev, int B, int Cin, int H, int W,
-                   const float* w_host, const float* bias_host, int Cout, int transpose_flip, float* y_nchw_dev);
+                   const float* w_host, const float* bias_host, int Cout, int transpose_flip, float* y_nchw_dev,
+                   int storage_out /* 0: fp32 NHWC epilogue (output heads); 1: storage-dtype epilogue (UNet-internal) */);
 int kdip_test_groupnorm(void* stream, int dtype, const float* x_nchw_dev, int B, int C, int H, int W,
                         const float* gamma_host, const float* beta_host, const float* film_host, int silu,
                         float* y_nchw_dev, const float* dy_nchw_dev, float* dx_nchw_dev);

@@ -56,7 +56,7 @@ SIGNATURES = {
     "kdip_profile_report": (C.c_int, [VP, VP, VP, VP]),
     "kdip_profile_dump": (C.c_int, [C.c_char_p]),
     "kdip_debug_conv_timing": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, C.c_int]),
-    "kdip_test_conv": (C.c_int, [VP, C.c_int, C.c_int, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, C.c_int, C.c_int, VP]),
+    "kdip_test_conv": (C.c_int, [VP, C.c_int, C.c_int, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, C.c_int, C.c_int, VP, C.c_int]),
     "kdip_test_groupnorm": (C.c_int, [VP, C.c_int, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, VP, C.c_int, VP, VP, VP]),
 }
 

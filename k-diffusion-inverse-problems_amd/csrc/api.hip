@@ -183,7 +183,7 @@ static inline int pad32i(int c) { return (c + 31) / 32 * 32; }
 int kdip_debug_conv_timing(void* dev_buf, int H, int cin, int cout, int st_mode) { return conv_debug_timing(dev_buf, H, cin, cout, st_mode); }
 
 int kdip_test_conv(void* stream, int dtype, int ntaps, const float* x_nchw, int B, int Cin, int H, int W, const float* w_host,
-                   const float* bias_host, int Cout, int transpose_flip, float* y_nchw) {
+                   const float* bias_host, int Cout, int transpose_flip, float* y_nchw, int storage_out) {
   hipStream_t st = ST(stream);
   DType dt = dtype == KDIP_BF16 ? DT_BF16 : DT_F32;
   size_t es = dt == DT_BF16 ? 2 : 4;
@@ -192,18 +192,24 @@ int kdip_test_conv(void* stream, int dtype, int ntaps, const float* x_nchw, int 
   const int cpad = pad32i(Ci);
   std::vector<char> buf(packed_weight_bytes(dt, ntaps, cpad, Co));
   pack_conv_weight(dt, w_host, Cout, Cin, ntaps, transpose_flip, cpad, buf.data());
-  void *wp = nullptr, *xin = nullptr; float *bias = nullptr, *y32 = nullptr;
+  void *wp = nullptr, *xin = nullptr, *ys = nullptr; float *bias = nullptr, *y32 = nullptr;
   KDIP_HIP_CHECK(hipMalloc(&wp, buf.size()));
   KDIP_HIP_CHECK(hipMemcpy(wp, buf.data(), buf.size(), hipMemcpyHostToDevice));
   if (bias_host) { KDIP_HIP_CHECK(hipMalloc((void**)&bias, sizeof(float) * Co)); KDIP_HIP_CHECK(hipMemcpy(bias, bias_host, sizeof(float) * Co, hipMemcpyHostToDevice)); }
   KDIP_HIP_CHECK(hipMalloc(&xin, es * (size_t)B * H * W * cpad));
   const int opad = pad32i(Co);
-  KDIP_HIP_CHECK(hipMalloc((void**)&y32, sizeof(float) * (size_t)B * H * W * opad));
   int rc = nchw_to_nhwc(st, dt, x_nchw, B, Ci, H, W, 1.f, xin, cpad, cpad);
-  if (!rc) rc = conv_forward(st, dt, ntaps, xin, cpad, B, H, W, cpad, wp, bias, Co, y32, opad, nullptr, 0, 1, 1.f);
-  if (!rc) rc = nhwc_to_nchw_f32(st, y32, opad, B, Co, H, W, y_nchw);
+  if (storage_out) {     // the UNet-internal epilogues: output in the storage dtype
+    KDIP_HIP_CHECK(hipMalloc(&ys, es * (size_t)B * H * W * opad));
+    if (!rc) rc = conv_forward(st, dt, ntaps, xin, cpad, B, H, W, cpad, wp, bias, Co, ys, opad, nullptr, 0, 0, 1.f);
+    if (!rc) rc = nhwc_T_to_nchw_f32(st, dt, ys, opad, B, Co, H, W, y_nchw);
+  } else {               // the fp32-output epilogue of the output heads / final input gradient
+    KDIP_HIP_CHECK(hipMalloc((void**)&y32, sizeof(float) * (size_t)B * H * W * opad));
+    if (!rc) rc = conv_forward(st, dt, ntaps, xin, cpad, B, H, W, cpad, wp, bias, Co, y32, opad, nullptr, 0, 1, 1.f);
+    if (!rc) rc = nhwc_to_nchw_f32(st, y32, opad, B, Co, H, W, y_nchw);
+  }
   hipError_t e = hipStreamSynchronize(st);
-  (void)hipFree(wp); (void)hipFree(xin); (void)hipFree(y32); if (bias) (void)hipFree(bias);
+  (void)hipFree(wp); (void)hipFree(xin); if (y32) (void)hipFree(y32); if (ys) (void)hipFree(ys); if (bias) (void)hipFree(bias);
   if (rc) return rc;
   KDIP_HIP_CHECK(e);
   return KDIP_OK;

@@ -42,9 +42,10 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("storage_out", [0, 1])   # fp32-output head epilogue / storage-dtype (bf16 fast) epilogue
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_forward(lib, dtype, case):
+def test_conv_forward(lib, dtype, case, storage_out):
     B, Cin, Cout, H, W, ntaps = case
     g = torch.Generator().manual_seed(hash(case) % 1000)
     k = 3 if ntaps == 9 else 1
@@ -55,7 +56,8 @@ def test_conv_forward(lib, dtype, case):
     xd = x.cuda()
     y = torch.empty(B, Cout, H, W, device="cuda")
     lib.check(lib.load().kdip_test_conv(lib.stream(), dtype, ntaps, lib.ptr(xd), B, Cin, H, W,
-                                        C.c_void_p(w.contiguous().data_ptr()), C.c_void_p(b.data_ptr()), Cout, 0, lib.ptr(y)))
+                                        C.c_void_p(w.contiguous().data_ptr()), C.c_void_p(b.data_ptr()), Cout, 0, lib.ptr(y),
+                                        storage_out))
     assert rel_err(y.cpu(), ref) < TOL[dtype], case
 
 
@@ -73,7 +75,7 @@ def test_conv_dgrad(lib, dtype, case):
     gd = go.cuda()
     y = torch.empty(B, Cin, H, W, device="cuda")
     lib.check(lib.load().kdip_test_conv(lib.stream(), dtype, ntaps, lib.ptr(gd), B, Cin, H, W,
-                                        C.c_void_p(w.contiguous().data_ptr()), None, Cout, 1, lib.ptr(y)))
+                                        C.c_void_p(w.contiguous().data_ptr()), None, Cout, 1, lib.ptr(y), 0))
     assert rel_err(y.cpu(), ref) < TOL[dtype], case
 
 

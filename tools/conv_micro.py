@@ -1,5 +1,5 @@
 """Micro-benchmark of one implicit-GEMM conv shape through the C-ABI test hook (for rocprofv3 --pmc
-runs on the dominant kernel).  usage: python tools/conv_micro.py B Cin Cout H W ntaps reps"""
+runs on the dominant kernel; storage-dtype output = the UNet-internal bf16 epilogue).  usage: python tools/conv_micro.py B Cin Cout H W ntaps reps"""
 import ctypes as C, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import kdip_amd._lib as L
@@ -12,6 +12,6 @@ w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * ntaps) ** 0.5).contiguou
 b = torch.randn(Cout, generator=g)
 y = torch.empty(B, Cout, H, W, device="cuda")
 for _ in range(reps):
-    L.check(lib.kdip_test_conv(L.stream(), 1, ntaps, L.ptr(x), B, Cin, H, W, C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), Cout, 0, L.ptr(y)))
+    L.check(lib.kdip_test_conv(L.stream(), 1, ntaps, L.ptr(x), B, Cin, H, W, C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), Cout, 0, L.ptr(y), 1))
 torch.cuda.synchronize()
 print("done", float(y.abs().mean()))

@@ -1,0 +1,47 @@
+"""Fold the rocprofv3 --pmc passes of tools/pmc_conv.sh (gpurun_out/pmc_{a..e}/) into profiles/pmc_conv3x3_latest.json,
+the file bench.py's roofline.traffic reads.  HBM bytes follow MI355X_MICROARCH.md: FETCH_SIZE (KiB) x 2 on gfx950 for wide
+coalesced reads; WRITE_SIZE (KiB) as reported (it matched the algorithmic write bytes exactly in calibration).
+usage: python tools/pmc_to_json.py <batch>"""
+import csv, glob, json, os, sys, collections
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+KERNEL = "conv_igemm_kernel<unsigned short, 9, 2, 2, 2, 2, 1>"
+vals = collections.defaultdict(list)
+durs = []
+for d in "abcde":
+    for f in glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_{d}", "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if KERNEL in r["Kernel_Name"]:
+                vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                    durs.append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-9)
+if not vals:
+    sys.exit("no counter rows for " + KERNEL)
+m = {k: sum(v) / len(v) for k, v in vals.items()}          # mean over the launches of the micro-benchmark
+H = W = 256; Cin = Cout = 128
+alg_read = B * H * W * Cin * 2 + 9 * Cin * Cout * 2
+alg_write = B * H * W * Cout * 2
+rd = m["FETCH_SIZE"] * 1024 * 2
+wr = m["WRITE_SIZE"] * 1024
+out = {
+    "kernel": "conv_igemm_kernel<bf16,9,2,2,2,2,1>",
+    "shape": f"B={B}, 128->128 ch, 256x256, 3x3, bf16 in / bf16 out (tools/conv_micro.py, storage-dtype epilogue)",
+    "algorithmic_read_bytes": alg_read, "algorithmic_write_bytes": alg_write,
+    "FETCH_SIZE_KiB_raw": m["FETCH_SIZE"], "hbm_read_bytes_corrected_x2": rd,
+    "WRITE_SIZE_KiB_raw": m["WRITE_SIZE"], "hbm_write_bytes": wr,
+    "hbm_bytes_per_launch": rd + wr, "traffic_over_algorithmic": (rd + wr) / (alg_read + alg_write),
+    # SQ_VALU_MFMA_BUSY_CYCLES = 32 cycles x SQ_INSTS_MFMA summed over the 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+    "mfma_busy_frac": m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * m["GRBM_GUI_ACTIVE"] / 8),
+    "shader_clock_ghz_during_kernel": (m["GRBM_GUI_ACTIVE"] / 8) / (sum(durs) / len(durs)) / 1e9 if durs else None,
+    "lds_bank_conflict_frac_of_lds_active": m["SQ_LDS_BANK_CONFLICT"] / m["SQ_LDS_IDX_ACTIVE"] if "SQ_LDS_IDX_ACTIVE" in m else None,
+    "l2_hit_rate": m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"]) if "TCC_HIT_sum" in m else None,
+    "sq_wait_any_frac": m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"] if "SQ_WAVE_CYCLES" in m else None,
+    "sq_wait_inst_any_frac": m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"] if "SQ_WAVE_CYCLES" in m else None,
+    "sq_active_inst_any_frac": m["SQ_ACTIVE_INST_ANY"] / m["SQ_WAVE_CYCLES"] if "SQ_WAVE_CYCLES" in m else None,
+    "raw_counter_means": m,
+    "note": "separate rocprofv3 --pmc passes (tools/pmc_conv.sh); halo re-reads are absorbed by L2, so traffic ~= algorithmic bytes",
+    "shape_key": f"conv3x3_igemm_128x128|{B}|256|128|128",
+    "hbm_bytes_per_launch_bf16_out": rd + wr,
+}
+json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_conv3x3_latest.json"), "w"), indent=1)
+print(json.dumps({k: out[k] for k in ("hbm_bytes_per_launch", "traffic_over_algorithmic", "mfma_busy_frac", "l2_hit_rate", "lds_bank_conflict_frac_of_lds_active")}))
