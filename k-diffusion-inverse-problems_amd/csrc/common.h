@@ -105,6 +105,12 @@ __device__ inline float silu_grad_fast(float z) {
   return s * (1.f + z * (1.f - s));
 }
 
+// storage-type dispatch: bf16 tensors take the v_rcp_f32 forms (the IEEE division is ~10 extra VALU ops per element,
+// enough to make the GroupNorm streaming kernels VALU- instead of HBM-bound); f32 (parity mode) keeps IEEE division
+__device__ inline float silu_fast(float z) { return z * __builtin_amdgcn_rcpf(1.f + __expf(-z)); }
+template <typename T> __device__ inline float silu_T(float z) { return sizeof(T) == 2 ? silu_fast(z) : silu_f(z); }
+template <typename T> __device__ inline float silu_grad_T(float z) { return sizeof(T) == 2 ? silu_grad_fast(z) : silu_grad_f(z); }
+
 __device__ inline float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

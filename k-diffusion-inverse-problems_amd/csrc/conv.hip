@@ -589,7 +589,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               float z = ca[e] * xv[e] + cb[e];
-              float dz = p.st_silu ? vv[e] * silu_grad_f(z) : vv[e];
+              float dz = p.st_silu ? vv[e] * silu_grad_T<T>(z) : vv[e];
               float adz = ca[e] * dz;
               s1 += adz;
               s2 += adz * (xv[e] - gmean) * grstd;

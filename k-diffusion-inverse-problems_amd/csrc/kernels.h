@@ -55,6 +55,9 @@ int gn_bwd_apply(hipStream_t st, DType dt, const void* x, long ldx, const void* 
 // GN apply (+SiLU) fused with the 2x2 average pool of both the activated tensor (yp) and the raw input (xp)
 int gn_apply_pool2(hipStream_t st, DType dt, const void* x, long ldx, const float* coef, int B, int H, int W, int C, int silu,
                    void* yp, long ldy, void* xp, long ldxp);
+// GroupNorm statistics of a channel concat from its two producers' statistics (group boundaries must nest)
+bool gn_merge_eligible(int C1, int C2);
+int gn_merge_stats(hipStream_t st, const double* s1, int C1, const double* s2, int C2, int B, double* out);
 // small feature maps (HW <= 256): stats + coefficients + apply in one launch, one block per (image, group)
 bool gn_small_eligible(DType dt, long HW, int C);
 int gn_fwd_small(hipStream_t st, DType dt, const void* x, long ldx, int B, long HW, int C, const float* gamma,

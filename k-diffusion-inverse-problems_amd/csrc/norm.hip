@@ -100,6 +100,34 @@ int gn_stats(hipStream_t st, DType dt, const void* x, long ldx, int B, long HW, 
   return KDIP_OK;
 }
 
+// ---------------------------------------------------------------- statistics of a concat ----
+// GroupNorm over cat = [t1 (C1 ch) | t2 (C2 ch)]: when every merged group is a whole number of t1's or t2's groups,
+// its (sum, sum of squares) is the sum of the producers' conv-fused statistics -- no pass over the concat buffer.
+bool gn_merge_eligible(int C1, int C2) {
+  const int C = C1 + C2;
+  if (C1 <= 0 || C2 <= 0 || C1 % 32 || C2 % 32 || C % 32) return false;
+  const int cpg = C / 32;
+  return C1 % cpg == 0 && cpg % (C1 / 32) == 0 && cpg % (C2 / 32) == 0;
+}
+__global__ void gn_merge_stats_kernel(const double* __restrict__ s1, int C1, const double* __restrict__ s2, int C2, int B,
+                                      double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * 32) return;
+  const int b = i / 32, g = i % 32, cpg = (C1 + C2) / 32, c0 = g * cpg;
+  const double* src = c0 < C1 ? s1 + (long)b * 64 : s2 + (long)b * 64;
+  const int cpgs = (c0 < C1 ? C1 : C2) / 32, g0 = (c0 < C1 ? c0 : c0 - C1) / cpgs;
+  double a = 0, q = 0;
+  for (int k = 0; k < cpg / cpgs; ++k) { a += src[(g0 + k) * 2]; q += src[(g0 + k) * 2 + 1]; }
+  out[(long)i * 2] = a;
+  out[(long)i * 2 + 1] = q;
+}
+int gn_merge_stats(hipStream_t st, const double* s1, int C1, const double* s2, int C2, int B, double* out) {
+  KDIP_REQUIRE(gn_merge_eligible(C1, C2), "groupnorm: statistics of %d + %d channels cannot be merged", C1, C2);
+  hipLaunchKernelGGL(gn_merge_stats_kernel, dim3(cdiv((long)B * 32, 256)), dim3(256), 0, st, s1, C1, s2, C2, B, out);
+  KDIP_LAUNCH_CHECK();
+  return KDIP_OK;
+}
+
 // ------------------------------------------------------------------------- coefficients ----
 __global__ void gn_coef_kernel(const double* __restrict__ stats, const float* __restrict__ gamma,
                                const float* __restrict__ beta, const float* __restrict__ film, long film_ld, int B,
@@ -158,7 +186,7 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, long ldx, const float* 
 #pragma unroll
     for (int e = 0; e < EPV; ++e) {
       float z = ca[e] * f[e] + cb[e];
-      f[e] = silu ? silu_f(z) : z;
+      f[e] = silu ? silu_T<T>(z) : z;
     }
     *(uint4*)(yb + p * ldy) = pack16<T>(f);
   }
@@ -219,7 +247,7 @@ __global__ void gn_apply_pool2_kernel(const T* __restrict__ x, long ldx, const f
 #pragma unroll
       for (int e = 0; e < EPV; ++e) {
         const float z = ca[e] * f[e] + cb[e];
-        sy[e] += silu ? silu_f(z) : z;
+        sy[e] += silu ? silu_T<T>(z) : z;
         sx[e] += f[e];
       }
     }
@@ -286,7 +314,7 @@ __global__ void gn_bwd_stats_kernel(const T* __restrict__ x, long ldx, const T* 
 #pragma unroll
       for (int e = 0; e < EPV; ++e) {
         float z = a[e] * fx[e] + bb[e];
-        float dz = (silu ? fd[e] * silu_grad_f(z) : fd[e]) * dscale;
+        float dz = (silu ? fd[e] * silu_grad_T<T>(z) : fd[e]) * dscale;
         float adz = a[e] * dz;
         t1[e] += adz;
         t2[e] += adz * (fx[e] - mean[e]) * rstd[e];
@@ -365,7 +393,7 @@ __global__ void gn_bwd_apply_kernel(const T* __restrict__ x, long ldx, const T* 
 #pragma unroll
     for (int e = 0; e < EPV; ++e) {
       float z = ca[e] * fx[e] + cb[e];
-      float dz = (silu ? fd[e] * silu_grad_f(z) : fd[e]) * dscale;
+      float dz = (silu ? fd[e] * silu_grad_T<T>(z) : fd[e]) * dscale;
       float r = ca[e] * dz - (k0[e] + k1[e] * fx[e]);
       if (ab) r += fa[e] * dscale;
       if (ab2) r += fa2[e];
@@ -467,7 +495,7 @@ __global__ __launch_bounds__(256) void gn_fwd_small_kernel(const T* __restrict__
 #pragma unroll
     for (int e = 0; e < EPV; ++e) {
       const float z = sa[v * EPV + e] * f[e] + sb[v * EPV + e];
-      f[e] = silu ? silu_f(z) : z;
+      f[e] = silu ? silu_T<T>(z) : z;
     }
     *(uint4*)(yb + (long)px * ldy + v * EPV) = pack16<T>(f);
   }
@@ -523,7 +551,7 @@ __global__ __launch_bounds__(256) void gn_bwd_small_kernel(const T* __restrict__
 #pragma unroll
     for (int e = 0; e < EPV; ++e) {
       const float a = sa[v * EPV + e], z = a * fx[e] + sb[v * EPV + e];
-      const float dz = silu ? fd[e] * silu_grad_f(z) : fd[e];
+      const float dz = silu ? fd[e] * silu_grad_T<T>(z) : fd[e];
       const float adz = a * dz;
       t1 += adz;
       t2 += adz * (fx[e] - mean) * rstd;
@@ -546,7 +574,7 @@ __global__ __launch_bounds__(256) void gn_bwd_small_kernel(const T* __restrict__
 #pragma unroll
     for (int e = 0; e < EPV; ++e) {
       const float a = sa[v * EPV + e], z = a * fx[e] + sb[v * EPV + e];
-      const float dz = silu ? fd[e] * silu_grad_f(z) : fd[e];
+      const float dz = silu ? fd[e] * silu_grad_T<T>(z) : fd[e];
       float r = a * dz - (k0 + k1 * fx[e]);
       if (ab) r += fa[e];
       if (ab2) r += fa2[e];

@@ -273,7 +273,19 @@ int gn_forward(Ctx& c, const void* x, long ldx, int B, long HW, const GnW& g, co
   double* stats = nullptr;
   auto it = c.u->fused_stats.find(std::make_pair(x, g.C));
   if (it != c.u->fused_stats.end()) stats = it->second;                      // accumulated by the producing conv
-  else {
+  if (!stats && ldx == g.C) {
+    // x = [t1 | t2] written in place by two convs that both accumulated statistics: merge them
+    for (auto lo = c.u->fused_stats.lower_bound(std::make_pair(x, 0)); lo != c.u->fused_stats.end() && lo->first.first == x; ++lo) {
+      const int C1 = lo->first.second, C2 = g.C - C1;
+      if (C2 <= 0 || !gn_merge_eligible(C1, C2)) continue;
+      auto hi = c.u->fused_stats.find(std::make_pair((const void*)((const char*)x + c.es * C1), C2));
+      if (hi == c.u->fused_stats.end()) continue;
+      stats = new_sums(c, B);
+      RUN(gn_merge_stats(c.st, lo->second, C1, hi->second, C2, B, stats));
+      break;
+    }
+  }
+  if (!stats) {
     stats = new_sums(c, B);
     RUN(gn_stats(c.st, c.dt, x, ldx, B, HW, g.C, stats, 1));
   }
