@@ -32,6 +32,7 @@ class ConditionDenoiser(nn.Module):
         super().__init__()
         self.operator = operator
         self.y, self.y_flatten = measurement
+        self._y1, self._yf1 = self.y, self.y_flatten          # as given (the reference only ever sees batch 1)
         self.guidance = guidance
         self.zeta = zeta
         self.lambda_ = lambda_
@@ -71,9 +72,23 @@ class ConditionDenoiser(nn.Module):
         return self.mat_solver(self.operator, self.y, x0_mean, var, self.ortho_tf)
 
     # -------------------------------------------------------------------- dispatch ----
+    def _bind_batch(self, B):
+        """A call handles B independent batch-1 problems: a batch-1 measurement is shared by all of them
+        (B posterior samples of one measurement, the reference's `-n`); otherwise batches must agree."""
+        if self.y.shape[0] == B:
+            return
+        if self._y1.shape[0] == B:
+            self.y, self.y_flatten = self._y1, self._yf1
+        elif self._y1.shape[0] == 1:
+            self.y = self._y1.expand(B, *self._y1.shape[1:]).contiguous()
+            self.y_flatten = self._yf1.expand(B, *self._yf1.shape[1:]).contiguous() if self._yf1 is not None else None
+        else:
+            raise ValueError(f"measurement batch {self._y1.shape[0]} does not match the sample batch {B}")
+
     def forward(self, x, sigma):
         L.require_gpu()
         x = x.detach().contiguous()
+        self._bind_batch(x.shape[0])
         g = self.guidance
         low = sigma_host(sigma) < self.mle_sigma_thres
         if g == "uncond":

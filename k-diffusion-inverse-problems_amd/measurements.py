@@ -90,6 +90,9 @@ class LinearOperator(ABC):
         batched on-device CG otherwise.  Sets self.cg_iters / self.cg_info (per sample)."""
         y, x0_mean = self._check(y), self._check(x0_mean)
         B = x0_mean.shape[0]
+        if y.shape[0] != B:
+            raise ValueError(f"solve: measurement batch {y.shape[0]} != estimate batch {B} (B independent problems per call; "
+                             "ConditionDenoiser broadcasts a batch-1 measurement)")
         self._set_ortho(ortho_code)
         mat = torch.empty_like(x0_mean)
         iters = (C.c_int * B)()

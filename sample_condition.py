@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Caller harness of the hot path: posterior sampling for a folder of images.
+
+Mirrors the reference's `sample_condition_openai.py` (flag names :74-100, model / operator
+construction from the same JSON / YAML keys :112-151, x_T = randn * sigma_max :187, churn
+constants :191, per-image metric dict + avg_metrics.yaml :196-213) on top of the MI355X path
+(`kdip_amd`).  Differences, all explicit:
+
+  * `--batch-size` > 1 is allowed: B independent batch-1 problems per call (the reference asserts 1).
+  * no checkpoint / dataset is obtainable offline, so `--synthetic-weights` (seeded random-init
+    weights of the configured architecture) and `--synthetic-data N` (seeded smooth images) stand in
+    for `--checkpoint` and the image folder; real ones are used when the paths exist.
+  * metrics: psnr + ssim (kdip_amd.metrics); lpips needs the VGG checkpoint and is omitted.
+  * one process per GPU: launch under `python -m torch.distributed.run` for multi-GPU; the samples of
+    an image are split over the ranks and all-gathered once (kdip_amd.evaluation.compute_features).
+"""
+import argparse
+import json
+import os
+from functools import partial
+
+import torch
+import yaml
+
+import kdip_amd  # noqa: F401  (alias loader for the package directory)
+import kdip_amd.condition as kc
+import kdip_amd.evaluation as ke
+import kdip_amd.measurements as km
+import kdip_amd.metrics as kmet
+import kdip_amd.sampling as ks
+import kdip_amd.unet as ku
+
+
+def load_yaml(path):
+    with open(path) as f:
+        return yaml.load(f, Loader=yaml.FullLoader)
+
+
+def save_yaml(data, path):
+    with open(path, "w") as f:
+        yaml.dump(data, f)
+
+
+def folder_of_images(root):
+    """K.utils.FolderOfImages + ToTensor + (x*2-1) (sample_condition_openai.py:138-143): sorted image files -> [3,H,W] in [-1,1]."""
+    import numpy as np
+    from PIL import Image
+    exts = {".jpg", ".jpeg", ".png", ".ppm", ".bmp", ".pgm", ".tif", ".tiff", ".webp"}
+    paths = sorted(os.path.join(d, f) for d, _, fs in os.walk(root) for f in fs if os.path.splitext(f)[1].lower() in exts)
+    for p in paths:
+        img = np.asarray(Image.open(p).convert("RGB"), dtype=np.float32) / 255.0
+        yield torch.from_numpy(img).permute(2, 0, 1).contiguous() * 2 - 1
+
+
+def synthetic_images(n, size):
+    """seeded smooth fields in [-1,1]: clamp(3 * avgpool9x9(rand*2-1, circular), -1, 1)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(1)
+    for _ in range(n):
+        x = torch.rand(1, 3, size, size, generator=g) * 2 - 1
+        x = F.avg_pool2d(F.pad(x, (4, 4, 4, 4), mode="circular"), 9, stride=1)
+        yield (3 * x).clamp(-1, 1)[0]
+
+
+def to_pil_image(x):
+    """K.utils.to_pil_image: [-1,1] CHW -> 8-bit RGB."""
+    from PIL import Image
+    a = ((x.detach().float().cpu().clamp(-1, 1) + 1) / 2 * 255).round().to(torch.uint8).permute(1, 2, 0).numpy()
+    return Image.fromarray(a)
+
+
+def main():
+    p = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    p.add_argument("--batch-size", type=int, default=1, help="the batch size (samples per sampler call)")
+    p.add_argument("--checkpoint", type=str, default="../model_zoo/diffusion_ffhq_10m.pt", help="the checkpoint to use")
+    p.add_argument("--config", type=str, default="configs/test_ffhq.json", help="the model config")
+    p.add_argument("--operator-config", type=str, default="configs/inpainting_config.yaml")
+    p.add_argument("-n", type=int, default=1, help="the number of images to sample per measurement")
+    p.add_argument("--prefix", type=str, default="out", help="the output prefix")
+    p.add_argument("--logdir", type=str, default=os.path.join("runs", "sample_condition", "temp"))
+    p.add_argument("--save-img", dest="save_img", action="store_true")
+    # sampler
+    p.add_argument("--steps", type=int, default=50, help="the number of denoising steps")
+    p.add_argument("--ode", dest="ode", action="store_true")
+    p.add_argument("--euler", dest="euler", action="store_true")
+    # guidance
+    p.add_argument("--guidance", type=str, default="I")
+    p.add_argument("--xstart-cov-type", type=str, choices=["analytic", "convert", "pgdm", "dps", "diffpir", "tmpd"], default="convert")
+    p.add_argument("--mle-sigma-thres", type=float, default=0.2)
+    p.add_argument("--lam", type=float, default=None)
+    p.add_argument("--zeta", type=float, default=None)
+    p.add_argument("--num-hutchinson-samples", type=int, default=None)
+    p.add_argument("--eta", type=float, default=None)
+    # MI355X build only
+    p.add_argument("--dtype", choices=["bf16", "f32"], default="bf16", help="UNet storage / MFMA type (f32 = parity mode)")
+    p.add_argument("--synthetic-weights", action="store_true", help="seeded random-init weights when the checkpoint is absent")
+    p.add_argument("--synthetic-data", type=int, default=0, metavar="N", help="N seeded smooth images when the dataset folder is absent")
+    p.add_argument("--seed", type=int, default=0)
+    args = p.parse_args()
+
+    config = json.load(open(args.config))
+    model_config, dataset_config = config["model"], config["dataset"]
+    assert len(model_config["input_size"]) == 2 and model_config["input_size"][0] == model_config["input_size"][1]
+    size = model_config["input_size"]
+
+    env = ke.DistEnv()
+    device = env.device
+    if env.is_main_process:
+        print("Using device:", device, flush=True)
+
+    inner_model, diffusion = ku.create_model_and_diffusion(image_size=size[0], dtype=args.dtype, device=device, **model_config["openai"])
+    if os.path.exists(args.checkpoint):
+        sd = torch.load(args.checkpoint, map_location="cpu")
+        sd = sd.get("state_dict", sd) if isinstance(sd, dict) else sd
+    elif args.synthetic_weights:
+        sd = ku.synthetic_state_dict(seed=args.seed, image_size=size[0], model_channels=model_config["openai"]["num_channels"],
+                                     num_res_blocks=model_config["openai"]["num_res_blocks"],
+                                     attention_resolutions=model_config["openai"]["attention_resolutions"])
+    else:
+        raise FileNotFoundError(f"checkpoint {args.checkpoint} not found (pass --synthetic-weights for random-init weights)")
+    inner_model.load_state_dict(sd)
+    sigma_min, sigma_max = model_config["sigma_min"], model_config["sigma_max"]
+
+    if os.path.isdir(dataset_config["location"]):
+        images = folder_of_images(dataset_config["location"])
+    elif args.synthetic_data > 0:
+        images = synthetic_images(args.synthetic_data, size[0])
+    else:
+        raise FileNotFoundError(f"dataset folder {dataset_config['location']} not found (pass --synthetic-data N)")
+
+    operator_config = load_yaml(args.operator_config)
+    operator = km.get_operator(device=device, **operator_config)
+    if env.is_main_process:
+        print(f"Operation: {operator_config['name']} / sigma_s: {operator_config['sigma_s']}")
+        os.makedirs(args.logdir, exist_ok=True)
+        save_yaml(vars(args), os.path.join(args.logdir, "args.yaml"))
+
+    sigmas = ks.get_sigmas_karras(args.steps, sigma_min, sigma_max, rho=7.0, device="cpu")
+    recon_mse = None
+    if args.xstart_cov_type == "analytic":
+        path = model_config.get("recon_mse", "")
+        if os.path.exists(path):
+            recon_mse = torch.load(path, map_location="cpu")
+        else:   # synthetic table when the estimator (kdip_amd.analytic_variance) has not been run
+            s = ks.get_sigmas_karras(1000, sigma_min, sigma_max, device="cpu")[:-1]
+            recon_mse = {"sigmas": s, "mse_list": s ** 2 / (1 + s ** 2) * 0.5}
+
+    torch.manual_seed(args.seed + env.rank)
+    metrics_list = []
+    for i, x0 in enumerate(images):
+        x0 = x0[None].to(device)
+        measurement = operator.forward(x0.clone(), flatten=True)
+        model = kc.ConditionOpenAIDenoiser(
+            inner_model=inner_model, diffusion=diffusion, operator=operator, measurement=measurement, guidance=args.guidance,
+            x0_cov_type=args.xstart_cov_type, recon_mse=recon_mse, lambda_=args.lam, zeta=args.zeta, eta=args.eta,
+            num_hutchinson_samples=args.num_hutchinson_samples, mle_sigma_thres=args.mle_sigma_thres, device=device)
+
+        def sample_fn(n):
+            x = torch.randn([n, model_config["input_channels"], size[0], size[1]], device=device) * sigma_max
+            sampler = partial(ks.sample_heun if not args.euler else ks.sample_euler, model, x, sigmas, disable=True)
+            if not args.ode:
+                return sampler(s_churn=80, s_tmin=0.05, s_tmax=50, s_noise=1.003)
+            return sampler()
+
+        hat_x0 = ke.compute_features(env, sample_fn, lambda x: x, args.n, args.batch_size)
+        metrics = kmet.compute_metrics(hat_x0, x0)
+        metrics_list.append(metrics)
+        if env.is_main_process:
+            print(i, metrics, flush=True)
+            if args.save_img:
+                to_pil_image(measurement[0][0]).save(os.path.join(args.logdir, f"{args.prefix}_img_{i}_measurement.png"))
+                for j, out in enumerate(hat_x0):
+                    to_pil_image(out).save(os.path.join(args.logdir, f"{args.prefix}_img_{i}_hat_x0_sample_{j}.png"))
+
+    avg_metrics = kmet.calculate_average_metric(metrics_list)
+    if env.is_main_process:
+        print(avg_metrics)
+        save_yaml(avg_metrics, os.path.join(args.logdir, "avg_metrics.yaml"))
+    env.barrier()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,32 @@
+"""GPU: the caller harness (sample_condition.py, the stand-in for sample_condition_openai.py) end to end on synthetic
+weights / data: every operator config parses, a short sampler run writes args.yaml, avg_metrics.yaml and PNGs."""
+import os
+import subprocess
+import sys
+
+import pytest
+import yaml
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("op,extra", [
+    ("gaussian_deblur", ["--guidance", "I", "--xstart-cov-type", "convert", "--ode"]),
+    ("inpainting", ["--guidance", "dps", "--xstart-cov-type", "dps", "--zeta", "1.0", "--euler", "--ode"]),
+    ("super_resolution_4x", ["--guidance", "II", "--xstart-cov-type", "pgdm"]),
+    ("motion_deblur", ["--guidance", "I", "--xstart-cov-type", "analytic", "--ode"]),
+])
+def test_harness_runs(tmp_path, op, extra):
+    logdir = str(tmp_path / op)
+    cmd = [sys.executable, os.path.join(ROOT, "sample_condition.py"), "--synthetic-weights", "--synthetic-data", "1",
+           "--config", os.path.join(ROOT, "configs", "test_ffhq.json"),
+           "--operator-config", os.path.join(ROOT, "configs", f"{op}_config.yaml"),
+           "--steps", "3", "--batch-size", "2", "-n", "2", "--save-img", "--logdir", logdir] + extra
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    avg = yaml.safe_load(open(os.path.join(logdir, "avg_metrics.yaml")))
+    assert set(avg) == {"psnr", "ssim"} and all(v == v and abs(v) < 1e6 for v in avg.values()), avg
+    assert os.path.exists(os.path.join(logdir, "args.yaml"))
+    pngs = [f for f in os.listdir(logdir) if f.endswith(".png")]
+    assert len(pngs) == 3, pngs          # 1 measurement + 2 samples

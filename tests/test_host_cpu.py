@@ -170,3 +170,40 @@ def test_compute_features_gloo_world2(tmp_path):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
+
+
+def test_metrics_psnr_ssim_against_scipy_restatement():
+    """kdip_amd.metrics (compute_metrics of the caller harness, sample_condition_openai.py:41-49): SSIM against an
+    independent scipy.ndimage restatement of skimage's algorithm (uniform 7x7 window, sample covariance, cropped mean,
+    channel average); PSNR against its definition; averaging helper."""
+    import numpy as np
+    from scipy.ndimage import uniform_filter
+    import kdip_amd.metrics as M
+    g = torch.Generator().manual_seed(4)
+    a = torch.rand(3, 40, 52, generator=g)
+    b = (a + 0.1 * torch.randn(3, 40, 52, generator=g)).clip(0, 1)
+
+    def ssim_ref(x, y, R=1.0, win=7):
+        vals = []
+        for c in range(x.shape[0]):
+            X, Y = x[c].astype(np.float64), y[c].astype(np.float64)
+            NP = win * win; cov = NP / (NP - 1.0)
+            ux, uy = uniform_filter(X, win), uniform_filter(Y, win)
+            vx = cov * (uniform_filter(X * X, win) - ux * ux)
+            vy = cov * (uniform_filter(Y * Y, win) - uy * uy)
+            vxy = cov * (uniform_filter(X * Y, win) - ux * uy)
+            C1, C2 = (0.01 * R) ** 2, (0.03 * R) ** 2
+            S = ((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux ** 2 + uy ** 2 + C1) * (vx + vy + C2))
+            p = (win - 1) // 2
+            vals.append(S[p:-p, p:-p].mean())
+        return float(np.mean(vals))
+
+    assert abs(M.structural_similarity(a, b) - ssim_ref(a.numpy(), b.numpy())) < 1e-9
+    assert abs(M.structural_similarity(a, a) - 1.0) < 1e-12
+    mse = float(((a.double() - b.double()) ** 2).mean())
+    assert abs(M.peak_signal_noise_ratio(a, b) - 10 * np.log10(1 / mse)) < 1e-9
+    x0 = (a * 2 - 1)[None]; hx = (b * 2 - 1)[None]
+    m = M.compute_metrics(hx, x0)
+    assert set(m) == {"psnr", "ssim"} and abs(m["psnr"] - M.peak_signal_noise_ratio(a, b)) < 1e-4
+    avg = M.calculate_average_metric([{"psnr": 1.0, "ssim": 0.5}, {"psnr": 3.0}])
+    assert avg == {"psnr": 2.0, "ssim": 0.5}

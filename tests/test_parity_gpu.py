@@ -270,6 +270,27 @@ def test_batch_semantics(gold, tiny):
         assert float((one - full[b:b + 1]).abs().max()) < 2e-4
 
 
+@pytest.mark.parametrize("name,guidance,cov,kw", [("gaussian_blur", "I", "convert", {}), ("inpainting", "dps", "dps", {"zeta": 1.0}),
+                                                  ("super_resolution", "II", "pgdm", {})])
+def test_shared_measurement_broadcast(gold, tiny, name, guidance, cov, kw):
+    """A batch-1 measurement is shared by all B samples of a call (B posterior samples of one measurement, the
+    harness' `-n`): identical to passing the measurement repeated B times; a mismatching batch is an error."""
+    import kdip_amd.condition as kc
+    models, D, sd, cfg = tiny
+    hop, oop, (y, yf), x0 = make_ops(name, gold)
+    y, yf = y.cuda(), yf.cuda()
+    g = torch.Generator().manual_seed(5)
+    xs = (x0 + 0.5 * torch.randn(3, 3, 64, 64, generator=g)).cuda()
+    sig = torch.full((3,), 0.5, device="cuda")
+    mk = lambda meas: kc.ConditionOpenAIDenoiser(inner_model=models["f32"], diffusion=D, x0_cov_type=cov, recon_mse=None, operator=hop,
+                                                 measurement=meas, guidance=guidance, device="cuda", **kw)
+    shared = mk((y, yf))(xs, sig)
+    rep = mk((y.repeat(3, 1, 1, 1), yf.repeat(3, 1)))(xs, sig)
+    assert float((shared - rep).abs().max()) < 1e-6
+    with pytest.raises(ValueError):
+        mk((y.repeat(2, 1, 1, 1), yf.repeat(2, 1)))(xs, sig)
+
+
 def test_error_behaviour(gold, tiny):
     import kdip_amd.condition as kc
     import kdip_amd.measurements as km
