@@ -6,6 +6,10 @@ construction from the same JSON / YAML keys :112-151, x_T = randn * sigma_max :1
 constants :191, per-image metric dict + avg_metrics.yaml :196-213) on top of the MI355X path
 (`kdip_amd`).  Differences, all explicit:
 
+  * `--v2` (or a config with `ortho_tf_type`) is the reference's second script, `sample_condition_openai_v2.py`:
+    `OpenAIDenoiserV2` with the `out_cov` log-variance head, `ConditionOpenAIDenoiserV2`, `--spatial-var`,
+    `--mle-sigma-thres` default 1 instead of 0.2 (:70-91,150-160).  The Lightning checkpoint it loads cannot be
+    unpickled here; a plain state_dict with `out_cov.*` keys (or `--synthetic-weights`) is used instead.
   * `--batch-size` > 1 is allowed: B independent batch-1 problems per call (the reference asserts 1).
   * no checkpoint / dataset is obtainable offline, so `--synthetic-weights` (seeded random-init
     weights of the configured architecture) and `--synthetic-data N` (seeded smooth images) stand in
@@ -86,11 +90,13 @@ def main():
     # guidance
     p.add_argument("--guidance", type=str, default="I")
     p.add_argument("--xstart-cov-type", type=str, choices=["analytic", "convert", "pgdm", "dps", "diffpir", "tmpd"], default="convert")
-    p.add_argument("--mle-sigma-thres", type=float, default=0.2)
+    p.add_argument("--mle-sigma-thres", type=float, default=None, help="default 0.2 (1 with --v2)")
     p.add_argument("--lam", type=float, default=None)
     p.add_argument("--zeta", type=float, default=None)
     p.add_argument("--num-hutchinson-samples", type=int, default=None)
     p.add_argument("--eta", type=float, default=None)
+    p.add_argument("--v2", action="store_true", help="the DWT-Var / DCT-Var path of sample_condition_openai_v2.py")
+    p.add_argument("--spatial-var", dest="spatial_var", action="store_true", help="(v2) pixel-space instead of transform-space variance")
     # MI355X build only
     p.add_argument("--dtype", choices=["bf16", "f32"], default="bf16", help="UNet storage / MFMA type (f32 = parity mode)")
     p.add_argument("--synthetic-weights", action="store_true", help="seeded random-init weights when the checkpoint is absent")
@@ -100,6 +106,9 @@ def main():
 
     config = json.load(open(args.config))
     model_config, dataset_config = config["model"], config["dataset"]
+    v2 = args.v2 or "ortho_tf_type" in model_config
+    if args.mle_sigma_thres is None:
+        args.mle_sigma_thres = 1.0 if v2 else 0.2
     assert len(model_config["input_size"]) == 2 and model_config["input_size"][0] == model_config["input_size"][1]
     size = model_config["input_size"]
 
@@ -113,7 +122,7 @@ def main():
         sd = torch.load(args.checkpoint, map_location="cpu")
         sd = sd.get("state_dict", sd) if isinstance(sd, dict) else sd
     elif args.synthetic_weights:
-        sd = ku.synthetic_state_dict(seed=args.seed, image_size=size[0], model_channels=model_config["openai"]["num_channels"],
+        sd = ku.synthetic_state_dict(seed=args.seed, out_cov=v2, image_size=size[0], model_channels=model_config["openai"]["num_channels"],
                                      num_res_blocks=model_config["openai"]["num_res_blocks"],
                                      attention_resolutions=model_config["openai"]["attention_resolutions"])
     else:
@@ -150,10 +159,18 @@ def main():
     for i, x0 in enumerate(images):
         x0 = x0[None].to(device)
         measurement = operator.forward(x0.clone(), flatten=True)
-        model = kc.ConditionOpenAIDenoiser(
-            inner_model=inner_model, diffusion=diffusion, operator=operator, measurement=measurement, guidance=args.guidance,
-            x0_cov_type=args.xstart_cov_type, recon_mse=recon_mse, lambda_=args.lam, zeta=args.zeta, eta=args.eta,
-            num_hutchinson_samples=args.num_hutchinson_samples, mle_sigma_thres=args.mle_sigma_thres, device=device)
+        if v2:
+            from kdip_amd.external import OpenAIDenoiserV2
+            denoiser = OpenAIDenoiserV2(inner_model, diffusion, device=device, ortho_tf_type=model_config.get("ortho_tf_type"))
+            model = kc.ConditionOpenAIDenoiserV2(
+                denoiser=denoiser, operator=operator, measurement=measurement, guidance=args.guidance, device=device, zeta=args.zeta,
+                lambda_=args.lam, eta=args.eta, num_hutchinson_samples=args.num_hutchinson_samples, mle_sigma_thres=args.mle_sigma_thres,
+                ortho_tf_type=None if args.spatial_var else model_config.get("ortho_tf_type"))
+        else:
+            model = kc.ConditionOpenAIDenoiser(
+                inner_model=inner_model, diffusion=diffusion, operator=operator, measurement=measurement, guidance=args.guidance,
+                x0_cov_type=args.xstart_cov_type, recon_mse=recon_mse, lambda_=args.lam, zeta=args.zeta, eta=args.eta,
+                num_hutchinson_samples=args.num_hutchinson_samples, mle_sigma_thres=args.mle_sigma_thres, device=device)
 
         def sample_fn(n):
             x = torch.randn([n, model_config["input_channels"], size[0], size[1]], device=device) * sigma_max
