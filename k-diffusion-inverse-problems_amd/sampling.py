@@ -117,3 +117,34 @@ def sample_heun(model, x, sigmas, extra_args=None, callback=None, disable=None, 
     for i in _trange(len(sig) - 1, disable):
         x = heun_step(model, x, sig, i, extra_args, callback, sigmas, s_churn, s_tmin, s_tmax, s_noise)
     return x
+
+
+def sample_dpmpp_2m(model, x, sigmas, extra_args=None, callback=None, disable=None):
+    """DPM-Solver++(2M) (k_diffusion/sampling.py:583-605; the training-preview sampler, train_openai.py:114).
+    The log-sigma step arithmetic is fp32 on the host, as the reference does it on 0-d tensors; the update
+    x' = (sigma_next / sigma) x - expm1(-h) * ((1 + 1/2r) denoised - (1/2r) old_denoised) is two fused axpby kernels."""
+    extra_args = {} if extra_args is None else extra_args
+    lib = L.load()
+    x, sig = _prep(x, sigmas)
+    t_fn = lambda s: s.log().neg()
+    sigma_fn = lambda t: t.neg().exp()
+    old_denoised = None
+    for i in _trange(len(sig) - 1, disable):
+        denoised = model(x, _sigma_vec(x, sig[i]), **extra_args).contiguous()
+        if callback is not None:
+            callback({'x': x, 'i': i, 'sigma': sigmas[i], 'sigma_hat': sigmas[i], 'denoised': denoised})
+        t, t_next = t_fn(sig[i]), t_fn(sig[i + 1])
+        h = t_next - t
+        a = float(sigma_fn(t_next) / sigma_fn(t))
+        e = float((-h).expm1())
+        xn = torch.empty_like(x)
+        if old_denoised is None or sig[i + 1] == 0:
+            L.check(lib.kdip_axpby(L.stream(), L.ptr(x), a, L.ptr(denoised), -e, x.numel(), L.ptr(xn)))
+        else:
+            r = (t - t_fn(sig[i - 1])) / h
+            c1, c2 = float(1 + 1 / (2 * r)), float(1 / (2 * r))
+            tmp = torch.empty_like(x)
+            L.check(lib.kdip_axpby(L.stream(), L.ptr(x), a, L.ptr(denoised), -e * c1, x.numel(), L.ptr(tmp)))
+            L.check(lib.kdip_axpby(L.stream(), L.ptr(tmp), 1.0, L.ptr(old_denoised), e * c2, x.numel(), L.ptr(xn)))
+        x, old_denoised = xn, denoised
+    return x

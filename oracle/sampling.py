@@ -63,3 +63,26 @@ def psnr(hat_x0, x0):
     b = (x0 / 2 + 0.5).clip(0, 1)
     mse = ((a - b) ** 2).flatten(1).mean(dim=1)
     return 10 * torch.log10(1.0 / mse)
+
+
+def sample_dpmpp_2m(model, x, sigmas, callback=None):
+    """DPM-Solver++(2M), k_diffusion/sampling.py:583-605 (used by the training preview, train_openai.py:114)."""
+    s_in = x.new_ones([x.shape[0]])
+    t_fn = lambda sigma: sigma.log().neg()
+    sigma_fn = lambda t: t.neg().exp()
+    old_denoised = None
+    for i in range(len(sigmas) - 1):
+        denoised = model(x, sigmas[i] * s_in)
+        if callback is not None:
+            callback({"x": x, "i": i, "sigma": sigmas[i], "sigma_hat": sigmas[i], "denoised": denoised})
+        t, t_next = t_fn(sigmas[i]), t_fn(sigmas[i + 1])
+        h = t_next - t
+        if old_denoised is None or sigmas[i + 1] == 0:
+            x = (sigma_fn(t_next) / sigma_fn(t)) * x - (-h).expm1() * denoised
+        else:
+            h_last = t - t_fn(sigmas[i - 1])
+            r = h_last / h
+            denoised_d = (1 + 1 / (2 * r)) * denoised - (1 / (2 * r)) * old_denoised
+            x = (sigma_fn(t_next) / sigma_fn(t)) * x - (-h).expm1() * denoised_d
+        old_denoised = denoised
+    return x

@@ -209,3 +209,17 @@ def test_extra_guidance_and_analytic(gold):
     torch.manual_seed(9)
     est = oana.estimate_recon_mse(sd, cfg, [smooth_image(2, 64, 21), smooth_image(2, 64, 22)], T(ga["sigmas"]))
     assert float((est["mse_list"] - T(ga["mse_list"])).abs().max()) < 1e-5
+
+
+def test_sampler_dpmpp2m_trajectory(gold):
+    """oracle sample_dpmpp_2m (sampling.py:583-605) against the reference capture (5 steps, Type-I + Convert, tiny model)."""
+    g = gold("sampler_dpmpp2m")
+    cfg = ounet.UNetConfig(**ounet.TINY)
+    sd = ounet.init_state_dict(cfg, seed=0)
+    op, meas, _ = _ops_and_meas(gold, "gaussian_blur")
+    assert torch.equal(meas[0], T(g["y"]))                 # same measurement as the operator fixtures
+    first = []
+    m = ocond.GuidedDenoiser(sd, cfg, op, meas, "I", x0_cov_type="convert")
+    x = osamp.sample_dpmpp_2m(m, T(g["xT"]).clone(), T(g["sigmas"]), callback=lambda d: first.append(d["denoised"]))
+    assert float((first[0] - T(g["denoised_first"])).abs().max()) < 5e-4
+    assert float((x - T(g["x0"])).abs().max()) < 5e-4

@@ -344,6 +344,21 @@ def test_sampler_golden(gold, tiny):
         assert dp < 1e-3, (sampler, dp)
 
 
+def test_sampler_dpmpp2m_golden(gold, tiny):
+    """sample_dpmpp_2m on the HIP path (f32 mode) against the reference capture."""
+    import kdip_amd.condition as kc
+    import kdip_amd.sampling as ks
+    models, D, sd, cfg = tiny
+    g = gold("sampler_dpmpp2m")
+    hop, oop, (y, yf), x0 = make_ops("gaussian_blur", gold)
+    m = kc.ConditionOpenAIDenoiser(inner_model=models["f32"], diffusion=D, x0_cov_type="convert", recon_mse=None, operator=hop,
+                                   measurement=(y.cuda(), yf.cuda()), guidance="I", device="cuda")
+    first = []
+    x = ks.sample_dpmpp_2m(m, T(g["xT"]).cuda(), T(g["sigmas"]), disable=True, callback=lambda d: first.append(d["denoised"].cpu()))
+    assert float((first[0] - T(g["denoised_first"])).abs().max()) < 2e-3
+    assert float((x.cpu() - T(g["x0"])).abs().max()) < 5e-3
+
+
 def test_tmpd_stsl_golden(gold, tiny):
     """tmpd covariance (extra all-ones VJP) and STSL (one forward + VJP per Hutchinson probe) against the
     reference captures; probes are the same CPU-seeded eps the reference drew."""
