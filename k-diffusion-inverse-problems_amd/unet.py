@@ -139,6 +139,29 @@ class UNetModel:
         return int(self.lib.kdip_unet_workspace_bytes(self._h, B))
 
 
+def normalize_state_dict(obj, prefer_ema=True):
+    """Checkpoint payload -> flat UNet `state_dict` in the reference key layout.
+
+    * plain OpenAI checkpoints (`diffusion_ffhq_10m.pt`, `256x256_diffusion_uncond.pt`): returned as is;
+    * Lightning checkpoints of the DWT-Var / DCT-Var models (`ffhq_dwt.ckpt`, train_openai.py:86-87): the `state_dict`
+      entry with keys `model_ema.inner_model.*` / `model_ema.out_cov.*` (EMA copy, what
+      `OpenAIDenoiser.load_from_checkpoint(...).model_ema` serves, sample_condition_openai_v2.py:121) or `model.*`;
+      buffers that are not UNet parameters (sigmas, log_sigmas, EMA counters) are dropped.
+    """
+    sd = obj.get("state_dict", obj) if isinstance(obj, dict) else obj
+    roots = ("model_ema.", "model.") if prefer_ema else ("model.", "model_ema.")
+    for root in roots:
+        if any(k.startswith(root + "inner_model.") for k in sd):
+            out = {}
+            for k, v in sd.items():
+                if k.startswith(root + "inner_model."):
+                    out[k[len(root + "inner_model."):]] = v
+                elif k.startswith(root + "out_cov."):
+                    out["out_cov." + k[len(root + "out_cov."):]] = v
+            return out
+    return dict(sd)
+
+
 FFHQ_CONFIG = dict(image_size=256, model_channels=128, num_res_blocks=1, attention_resolutions="16")
 IMAGENET_CONFIG = dict(image_size=256, model_channels=256, num_res_blocks=2, attention_resolutions="8,16,32")
 

@@ -8,8 +8,8 @@ constants :191, per-image metric dict + avg_metrics.yaml :196-213) on top of the
 
   * `--v2` (or a config with `ortho_tf_type`) is the reference's second script, `sample_condition_openai_v2.py`:
     `OpenAIDenoiserV2` with the `out_cov` log-variance head, `ConditionOpenAIDenoiserV2`, `--spatial-var`,
-    `--mle-sigma-thres` default 1 instead of 0.2 (:70-91,150-160).  The Lightning checkpoint it loads cannot be
-    unpickled here; a plain state_dict with `out_cov.*` keys (or `--synthetic-weights`) is used instead.
+    `--mle-sigma-thres` default 1 instead of 0.2 (:70-91,150-160).  Its Lightning checkpoint is read through
+    `ku.normalize_state_dict` (`model_ema.inner_model.*` / `model_ema.out_cov.*` keys); `--synthetic-weights` otherwise.
   * `--batch-size` > 1 is allowed: B independent batch-1 problems per call (the reference asserts 1).
   * no checkpoint / dataset is obtainable offline, so `--synthetic-weights` (seeded random-init
     weights of the configured architecture) and `--synthetic-data N` (seeded smooth images) stand in
@@ -119,8 +119,7 @@ def main():
 
     inner_model, diffusion = ku.create_model_and_diffusion(image_size=size[0], dtype=args.dtype, device=device, **model_config["openai"])
     if os.path.exists(args.checkpoint):
-        sd = torch.load(args.checkpoint, map_location="cpu")
-        sd = sd.get("state_dict", sd) if isinstance(sd, dict) else sd
+        sd = ku.normalize_state_dict(torch.load(args.checkpoint, map_location="cpu"))   # plain .pt or Lightning .ckpt layout
     elif args.synthetic_weights:
         sd = ku.synthetic_state_dict(seed=args.seed, out_cov=v2, image_size=size[0], model_channels=model_config["openai"]["num_channels"],
                                      num_res_blocks=model_config["openai"]["num_res_blocks"],

@@ -207,3 +207,19 @@ def test_metrics_psnr_ssim_against_scipy_restatement():
     assert set(m) == {"psnr", "ssim"} and abs(m["psnr"] - M.peak_signal_noise_ratio(a, b)) < 1e-4
     avg = M.calculate_average_metric([{"psnr": 1.0, "ssim": 0.5}, {"psnr": 3.0}])
     assert avg == {"psnr": 2.0, "ssim": 0.5}
+
+
+def test_normalize_state_dict_layouts():
+    """plain OpenAI state_dict passes through; a Lightning-style payload (train_openai.py:86-87 key layout) is reduced to the
+    EMA UNet + out_cov keys the loader expects."""
+    import kdip_amd.unet as ku
+    w = torch.zeros(2)
+    plain = {"input_blocks.0.0.weight": w, "out.2.bias": w}
+    assert ku.normalize_state_dict(plain).keys() == plain.keys()
+    assert ku.normalize_state_dict({"state_dict": plain}).keys() == plain.keys()
+    lit = {"state_dict": {"model.inner_model.out.2.bias": w + 1, "model_ema.inner_model.out.2.bias": w + 2, "model_ema.out_cov.weight": w + 3,
+                          "model_ema.sigmas": w, "model.out_cov.weight": w, "ema_decay": w}}
+    got = ku.normalize_state_dict(lit)
+    assert set(got) == {"out.2.bias", "out_cov.weight"} and float(got["out.2.bias"][0]) == 2.0 and float(got["out_cov.weight"][0]) == 3.0
+    got = ku.normalize_state_dict(lit, prefer_ema=False)
+    assert float(got["out.2.bias"][0]) == 1.0
