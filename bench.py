@@ -1,11 +1,11 @@
 #!/usr/bin/env python
 """Benchmark of the hot path: BASELINE.json configs[1] -- FFHQ 256x256 Gaussian deblur, Type-I
-guidance with Convert posterior covariance, 100 Heun steps, batch 64 per MI355X (--batch).
+guidance with Convert posterior covariance, 100 Heun steps, batch 128 per MI355X (--batch).
 
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one Heun sampler step of the 100-step Karras schedule over one batch of 64 synthetic
+A "step" is one Heun sampler step of the 100-step Karras schedule over one batch of 128 synthetic
 images (2 guided-denoiser calls = 2 UNet forwards + 2 hand-written UNet VJPs + 2 mat-solves, CG
 on the sigma < 0.2 steps).  With K = 100 (default) the timed region is the whole sampler run; with
 K < 100 the K timed steps are spread evenly over the schedule (so the closed-form / CG mix is
@@ -105,7 +105,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="images per GPU")
+    ap.add_argument("--batch", type=int, default=128, help="images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
