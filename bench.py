@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Benchmark of the hot path: BASELINE.json configs[1] -- FFHQ 256x256 Gaussian deblur, Type-I
-guidance with Convert posterior covariance, 100 Heun steps, batch 128 per MI355X (--batch).
+guidance with Convert posterior covariance, 100 Heun steps, batch 128 per MI355X (--batch) run as
+--streams (2) independent part-batches on their own HIP streams / host threads.
 
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
@@ -106,6 +107,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=128, help="images per GPU")
+    ap.add_argument("--streams", type=int, default=2, help="part-batches per GPU, each on its own HIP stream + host thread")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -124,47 +126,80 @@ def main():
     B, S, rank = args.batch, 256, env.rank
     lib = L.load()
 
-    # ---- model (random-init weights of the named architecture; no checkpoint is obtainable offline)
-    model = ku.UNetModel(dtype="bf16", device=dev, **ku.FFHQ_CONFIG)
-    model.load_state_dict(ku.synthetic_state_dict(seed=0, **ku.FFHQ_CONFIG))
+    # ---- the per-GPU batch is split into `--streams` part-batches, each with its own UNet handle (weights + workspace),
+    # operator context, HIP stream and host thread: images are independent problems, so while one part is in its
+    # HBM-bound GroupNorm passes or waits for a CG convergence flag, the other part's convs have the MFMA pipes.
+    S_ = max(1, min(args.streams, B))
     D = ku.GaussianDiffusionTables()
-    # ---- operator + synthetic measurement (sigma_s = 0.05), rank-offset seeds: every image is its own problem
-    op = km.get_operator("gaussian_blur", device=dev, in_shape=(1, 3, S, S), kernel_size=61, intensity=3.0, sigma_s=0.05)
-    x0 = smooth_image(B, S, seed=1 + 1000 * rank).to(dev)
-    torch.manual_seed(2 + 1000 * rank)
-    meas = op.forward(x0.clone(), flatten=True)
-    den = kc.ConditionOpenAIDenoiser(inner_model=model, diffusion=D, x0_cov_type="convert", recon_mse=None, operator=op,
-                                     measurement=meas, guidance="I", mle_sigma_thres=0.2, device=dev).eval()
     sigmas = ks.get_sigmas_karras(100, 0.01, 80, rho=7.0, device=dev)
     sig = sigmas.detach().cpu()
-    noise = torch.randn(B, 3, S, S, device=dev, generator=torch.Generator(device=dev).manual_seed(3 + 1000 * rank))
+    sd = ku.synthetic_state_dict(seed=0, **ku.FFHQ_CONFIG)      # random-init weights of the named architecture (no checkpoint offline)
+    parts = []
+    for k in range(S_):
+        Bk = B // S_ + (1 if k < B % S_ else 0)
+        model = ku.UNetModel(dtype="bf16", device=dev, **ku.FFHQ_CONFIG)
+        model.load_state_dict(sd)
+        # operator + synthetic measurement (sigma_s = 0.05), rank- and part-offset seeds: every image is its own problem
+        op = km.get_operator("gaussian_blur", device=dev, in_shape=(1, 3, S, S), kernel_size=61, intensity=3.0, sigma_s=0.05)
+        x0 = smooth_image(Bk, S, seed=1 + 1000 * rank + 100 * k).to(dev)
+        torch.manual_seed(2 + 1000 * rank + 100 * k)
+        meas = op.forward(x0.clone(), flatten=True)
+        den = kc.ConditionOpenAIDenoiser(inner_model=model, diffusion=D, x0_cov_type="convert", recon_mse=None, operator=op,
+                                         measurement=meas, guidance="I", mle_sigma_thres=0.2, device=dev).eval()
+        noise = torch.randn(Bk, 3, S, S, device=dev, generator=torch.Generator(device=dev).manual_seed(3 + 1000 * rank + 100 * k))
+        parts.append(dict(den=den, x0=x0, noise=noise, stream=torch.cuda.Stream(device=dev) if S_ > 1 else torch.cuda.current_stream(), B=Bk))
+    torch.cuda.synchronize()
 
-    def start_state(i):
-        return (x0 + float(sig[i]) * noise).contiguous() if i > 0 else (noise * float(sig[0])).contiguous()
+    def start_state(pt, i):
+        return (pt["x0"] + float(sig[i]) * pt["noise"]).contiguous() if i > 0 else (pt["noise"] * float(sig[0])).contiguous()
 
     full_run = args.steps % 100 == 0 and args.steps > 0
     idx = step_indices(args.steps)
 
-    # ---- warm-up: one closed-form step and one CG step (allocates the workspaces)
-    for w in range(max(args.warmup, 0)):
-        i = 10 if w % 2 == 0 else 95
-        ks.heun_step(den, start_state(i), sig, i)
+    def run_part(pt, steps, chain, res, k):
+        try:
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(pt["stream"]):
+                x = start_state(pt, 0)
+                for i in steps:
+                    if not chain or i == 0:
+                        x = start_state(pt, i)
+                    x = ks.heun_step(pt["den"], x, sig, i)
+                res[k] = x
+        except BaseException as e:          # re-raised by the caller
+            res[k] = e
+
+    def run_all(steps, chain):
+        res = [None] * S_
+        if S_ == 1:
+            run_part(parts[0], steps, chain, res, 0)
+        else:
+            import threading
+            th = [threading.Thread(target=run_part, args=(parts[k], steps, chain, res, k)) for k in range(S_)]
+            for t in th: t.start()
+            for t in th: t.join()
+        for r in res:
+            if isinstance(r, BaseException):
+                raise r
+        torch.cuda.synchronize()
+        return torch.cat(res)
+
+    # ---- warm-up: one closed-form step and one CG step per warm-up pair (allocates the workspaces)
+    if args.warmup > 0:
+        run_all([10 if w % 2 == 0 else 95 for w in range(args.warmup)], False)
     torch.cuda.synchronize()
 
     # ---- timed region
     env.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    x = start_state(0)
-    for n, i in enumerate(idx):
-        if not full_run or i == 0:
-            x = start_state(i)
-        x = ks.heun_step(den, x, sig, i)
+    x = run_all(idx, full_run)
     hat = env.gather(x)                                   # the one collective of the path (RCCL all_gather)
     torch.cuda.synchronize()
     env.barrier()
     elapsed = env.max_over_ranks(time.perf_counter() - t0)
     assert torch.isfinite(hat).all()
+    den, x0 = parts[0]["den"], parts[0]["x0"]             # the roofline leg profiles part 0 alone
 
     ms_per_step = elapsed / args.steps * 1e3
     images_per_s = env.world_size * B / (ms_per_step * 100 / 1e3)
@@ -175,7 +210,8 @@ def main():
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic (seeded smooth images, random-init FFHQ-architecture weights)",
         "config": {"workload": "BASELINE configs[1]: FFHQ 256x256 Gaussian deblur (61x61 PSF, sigma_s=0.05), Type-I guidance, "
                                "Convert covariance (CG below sigma 0.2), 100 Heun steps (--ode), batch " + str(B) + " per GPU",
-                   "global_batch": env.world_size * B, "per_gpu_batch": B, "calls_per_image": CALLS_PER_IMAGE,
+                   "global_batch": env.world_size * B, "per_gpu_batch": B, "streams_per_gpu": S_, "images_per_launch": parts[0]["B"],
+                   "calls_per_image": CALLS_PER_IMAGE,
                    "timed_steps": "full 100-step sampler run" if full_run else "evenly spaced subset of the 100-step schedule",
                    "parallelism": f"dp{env.world_size} (independent images, one all_gather at the end)"},
         "achieved_tflops_whole_step": round(2 * B * FWD_VJP_GFLOP_PER_IMAGE_CALL / ms_per_step, 2),
@@ -185,7 +221,7 @@ def main():
     if not args.no_roofline and env.is_main_process:
         L.check(lib.kdip_profile_enable(1))
         for i in (10, 95):
-            ks.heun_step(den, start_state(i), sig, i)
+            ks.heun_step(den, start_state(parts[0], i), sig, i)
         torch.cuda.synchronize()
         n = lib.kdip_profile_num_classes()
         ms = (C.c_double * n)(); fl = (C.c_double * n)(); by = (C.c_double * n)(); la = (C.c_long * n)()

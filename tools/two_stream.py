@@ -1,4 +1,4 @@
-"""Experiment: batch 16 as two half-batches on two HIP streams (fills the chip while one half is in
+"""Experiment (usage: two_stream.py nsplit total_batch): a batch as nsplit part-batches on two HIP streams (fills the chip while one half is in
 its latency-bound small-spatial layers) vs one batch-16 stream."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,7 +16,8 @@ def make(B, seed):
     return den, x0, torch.randn(B, 3, 256, 256, device="cuda")
 
 nsplit = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-parts = [make(16 // nsplit, 1 + k) for k in range(nsplit)]
+BT = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+parts = [make(BT // nsplit, 1 + k) for k in range(nsplit)]
 streams = [torch.cuda.Stream() for _ in range(nsplit)]
 def run(i, reps):
     for _ in range(reps):
@@ -26,4 +27,4 @@ def run(i, reps):
 for i in (10, 95):
     run(i, 1); torch.cuda.synchronize()
     t = time.perf_counter(); run(i, 3); torch.cuda.synchronize()
-    print(f"nsplit={nsplit} step {i}: {(time.perf_counter()-t)/3*1e3:.2f} ms per 16-image step")
+    print(f"nsplit={nsplit} step {i}: {(time.perf_counter()-t)/3*1e3:.2f} ms per {BT}-image step")
