@@ -95,9 +95,6 @@ constexpr int KC = 32;            // input channels per B-pipeline stage (one ta
 #ifndef KDIP_TW
 #define KDIP_TW 16
 #endif
-#ifndef KDIP_BIG
-#define KDIP_BIG 0
-#endif
 #ifndef KDIP_ABL_NOSTAGE
 #define KDIP_ABL_NOSTAGE 0
 #endif
@@ -124,9 +121,6 @@ constexpr int KC = 32;            // input channels per B-pipeline stage (one ta
 #endif
 #ifndef KDIP_SUBS3
 #define KDIP_SUBS3 1
-#endif
-#ifndef KDIP_WLAYOUT
-#define KDIP_WLAYOUT 0
 #endif
 #ifndef KDIP_OCC
 #define KDIP_OCC 3
@@ -742,11 +736,8 @@ static int launch_T(ConvParams& p, hipStream_t st) {
   // Small-spatial layers (8x8 ... 32x32) are weight-streaming / latency bound: more, narrower
   // blocks spread the weight reads over more CUs.
   const long mt = cdiv((long)p.B * p.H * p.W, 128);
-  // 256x128 block (wave tile 128x64: every B fragment feeds 4 MFMAs, every A fragment 2 -> half the
-  // L1 operand traffic per MFMA of the 64x64 wave tile) when there is enough work for >= 2 blocks/CU
-  if (KDIP_BIG && sizeof(T) == 2 && NTAPS == 9 && npad >= 128 && (mt / 2) * cdiv(npad, 128) >= 512 && p.H * p.W >= 256)
-    return launch_cfg<T, NTAPS, 2, 2, 4, 2>(p, st);
-  if (KDIP_WLAYOUT && sizeof(T) == 2 && NTAPS == 9 && npad >= 128 && mt * cdiv(npad, 128) >= 512) return launch_cfg<T, NTAPS, 1, 4, 4, 1>(p, st);
+  // (a 256x128 block with 128x64 wave tiles and a 1x4 wave layout were measured and rejected: DESIGN.md section 5,
+  // tools/experiments/)
   if (npad >= 128 && mt * cdiv(npad, 128) >= 512) return launch_cfg<T, NTAPS, 2, 2, 2, 2>(p, st);
   if (npad >= 64 && mt * cdiv(npad, 64) >= 512) return launch_cfg<T, NTAPS, 2, 2, 2, 1>(p, st);
   if (npad >= 128 && mt * cdiv(npad, 32) < 256) return launch_cfg<T, NTAPS, 4, 1, 1, 1>(p, st);

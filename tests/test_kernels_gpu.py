@@ -36,7 +36,7 @@ CONV_CASES = [
     (2, 64, 192, 8, 8, 1),
     (5, 128, 256, 1, 1, 1),
     (1, 32, 32, 64, 64, 1),
-    (2, 32, 128, 256, 256, 9),     # large-M shapes select the 256x128 block tile
+    (2, 32, 128, 256, 256, 9),     # large-M shapes (>= 512 blocks): the 128x128 tile
     (2, 64, 256, 256, 256, 1),
     (32, 64, 128, 64, 64, 9),
     (4, 96, 256, 256, 256, 9),     # full-resolution layer shape: 3 K-chunks, two N tiles, 2048 blocks
