@@ -384,11 +384,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
       if (loff[i] >= 0) *(uint4*)(smem + buf * abuf_bytes + loff[i]) = areg[i];
   };
 
-  stage_load(0);
-  stage_write(0);
-  __syncthreads();
-  KDIP_STAMP(1);
-
   // B fragments are software-pipelined two stages (= one tap of one 32-channel sub-chunk) ahead in
   // registers; a stage index past the end is clamped to the last stage (one redundant L2 hit) so the
   // loop body has no branches.
@@ -402,8 +397,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
       for (int nt = 0; nt < NT; ++nt) dst[ks][nt] = *bptr(tp, (long)c32 * KS + ks, nt);
   };
   uint4 bq0[KS][NT], bq1[KS][NT], bq2[KS][NT];
+
+  // prologue: the first two B stages are requested together with the first patch, ahead of the LDS write + barrier
+  // (issued after the barrier their L2 latency sat exposed in front of the first MFMA)
+  stage_load(0);
   load_b(bq0, 0);
   if (KDIP_B_DEPTH == 2) load_b(bq1, 1);
+  stage_write(0);
+  __syncthreads();
+  KDIP_STAMP(1);
 
   // A fragments of the next (sub, tap) stage are read from LDS one stage ahead, so the ds_reads
   // of stage s+1 are in flight under the MFMAs of stage s.
