@@ -2,7 +2,8 @@
 """Caller harness of the hot path: posterior sampling for a folder of images.
 
 Mirrors the reference's `sample_condition_openai.py` (flag names :74-100, model / operator
-construction from the same JSON / YAML keys :112-151, x_T = randn * sigma_max :187, churn
+construction from the same JSON / YAML keys :112-151 -- the reference's own per-model / per-task config files can be passed as
+they are, `configs/models.json#<entry>` / `configs/tasks.yaml#<entry>` hold the BASELINE configurations in one file each, x_T = randn * sigma_max :187, churn
 constants :191, per-image metric dict + avg_metrics.yaml :196-213) on top of the MI355X path
 (`kdip_amd`).  Differences, all explicit:
 
@@ -36,8 +37,18 @@ import kdip_amd.unet as ku
 
 
 def load_yaml(path):
+    """`file.yaml` (one operator per file, the reference's layout) or `file.yaml#entry` (configs/tasks.yaml)."""
+    path, _, entry = path.partition("#")
     with open(path) as f:
-        return yaml.load(f, Loader=yaml.FullLoader)
+        cfg = yaml.load(f, Loader=yaml.FullLoader)
+    return cfg[entry] if entry else cfg
+
+
+def load_json(path):
+    """`file.json` (one model per file, the reference's layout) or `file.json#entry` (configs/models.json)."""
+    path, _, entry = path.partition("#")
+    cfg = json.load(open(path))
+    return cfg[entry] if entry else cfg
 
 
 def save_yaml(data, path):
@@ -77,8 +88,8 @@ def main():
     p = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     p.add_argument("--batch-size", type=int, default=1, help="the batch size (samples per sampler call)")
     p.add_argument("--checkpoint", type=str, default="../model_zoo/diffusion_ffhq_10m.pt", help="the checkpoint to use")
-    p.add_argument("--config", type=str, default="configs/test_ffhq.json", help="the model config")
-    p.add_argument("--operator-config", type=str, default="configs/inpainting_config.yaml")
+    p.add_argument("--config", type=str, default="configs/models.json#ffhq", help="the model config (file.json or file.json#entry)")
+    p.add_argument("--operator-config", type=str, default="configs/tasks.yaml#inpainting", help="file.yaml or file.yaml#entry")
     p.add_argument("-n", type=int, default=1, help="the number of images to sample per measurement")
     p.add_argument("--prefix", type=str, default="out", help="the output prefix")
     p.add_argument("--logdir", type=str, default=os.path.join("runs", "sample_condition", "temp"))
@@ -104,7 +115,7 @@ def main():
     p.add_argument("--seed", type=int, default=0)
     args = p.parse_args()
 
-    config = json.load(open(args.config))
+    config = load_json(args.config)
     model_config, dataset_config = config["model"], config["dataset"]
     v2 = args.v2 or "ortho_tf_type" in model_config
     if args.mle_sigma_thres is None:

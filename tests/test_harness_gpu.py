@@ -13,8 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("op,extra", [
     ("gaussian_deblur", ["--guidance", "I", "--xstart-cov-type", "convert", "--ode"]),
-    ("gaussian_deblur", ["--config", "configs/test_ffhq_dwt.json", "--guidance", "autoI", "--ode"]),     # v2 script: DWT-Var, CG in the DWT basis
-    ("inpainting", ["--config", "configs/test_ffhq_dct.json", "--guidance", "II", "--spatial-var"]),
+    ("gaussian_deblur", ["--config", "configs/models.json#ffhq_dwt", "--guidance", "autoI", "--ode"]),     # v2 script: DWT-Var, CG in the DWT basis
+    ("inpainting", ["--config", "configs/models.json#ffhq_dct", "--guidance", "II", "--spatial-var"]),
     ("inpainting", ["--guidance", "dps", "--xstart-cov-type", "dps", "--zeta", "1.0", "--euler", "--ode"]),
     ("super_resolution_4x", ["--guidance", "II", "--xstart-cov-type", "pgdm"]),
     ("motion_deblur", ["--guidance", "I", "--xstart-cov-type", "analytic", "--ode"]),
@@ -22,10 +22,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_harness_runs(tmp_path, op, extra):
     logdir = str(tmp_path / "out")
     cmd = [sys.executable, os.path.join(ROOT, "sample_condition.py"), "--synthetic-weights", "--synthetic-data", "1",
-           "--operator-config", os.path.join(ROOT, "configs", f"{op}_config.yaml"),
+           "--operator-config", "configs/tasks.yaml#" + op,
            "--steps", "3", "--batch-size", "2", "-n", "2", "--save-img", "--logdir", logdir] + extra
     if "--config" not in extra:
-        cmd += ["--config", "configs/test_ffhq.json"]
+        cmd += ["--config", "configs/models.json#ffhq"]
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     avg = yaml.safe_load(open(os.path.join(logdir, "avg_metrics.yaml")))

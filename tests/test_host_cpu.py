@@ -223,3 +223,22 @@ def test_normalize_state_dict_layouts():
     assert set(got) == {"out.2.bias", "out_cov.weight"} and float(got["out.2.bias"][0]) == 2.0 and float(got["out_cov.weight"][0]) == 3.0
     got = ku.normalize_state_dict(lit, prefer_ema=False)
     assert float(got["out.2.bias"][0]) == 1.0
+
+
+def test_harness_config_loaders(tmp_path):
+    """sample_condition.py reads `file#entry` (configs/tasks.yaml, configs/models.json) and the reference's one-config-per-file
+    layout, including `!!python/tuple` tags."""
+    import importlib.util, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "sample_condition.py")).read()
+    ns = {}
+    exec(compile(src[src.index("def load_yaml"):src.index("def folder_of_images")], "loaders", "exec"), {"yaml": __import__("yaml"), "json": __import__("json")}, ns)
+    t = ns["load_yaml"](os.path.join(root, "configs", "tasks.yaml#gaussian_deblur"))
+    assert t == {"name": "gaussian_blur", "in_shape": [1, 3, 256, 256], "kernel_size": 61, "intensity": 3.0, "sigma_s": 0.05}
+    assert set(ns["load_yaml"](os.path.join(root, "configs", "tasks.yaml"))) == {"gaussian_deblur", "motion_deblur", "super_resolution_4x", "inpainting"}
+    m = ns["load_json"](os.path.join(root, "configs", "models.json#imagenet"))
+    assert m["model"]["openai"] == {"num_channels": 256, "num_res_blocks": 2, "attention_resolutions": "8,16,32"}
+    f = tmp_path / "one.yaml"
+    f.write_text("name: super_resolution\nin_shape: !!python/tuple [1, 3, 256, 256]\nscale_factor: 4\nsigma_s: 0.05\n")
+    one = ns["load_yaml"](str(f))
+    assert one["in_shape"] == (1, 3, 256, 256) and one["scale_factor"] == 4
