@@ -116,7 +116,7 @@ def test_baseline_config_shapes_run(cid, cfg, opn, guid, cov, extra, ortho, samp
 
 def test_unet_vjp_properties_fullsize():
     """Size-independent properties of the hand-written input-VJP at full size (FFHQ, f32 mode, batch 2):
-    linearity in the cotangent, and <c, J v> from a central finite difference of the forward == <J^T c, v>."""
+    linearity in the cotangent, and <c, J v> from a central finite difference of the forward == <J^T c, v> (checked over repeated runs: the forward has fp64-atomic-order noise ~1e-7)."""
     import kdip_amd.unet as ku
     m = ku.UNetModel(dtype="f32", **ku.FFHQ_CONFIG)
     m.load_state_dict(ku.synthetic_state_dict(seed=0, **ku.FFHQ_CONFIG))
@@ -129,9 +129,8 @@ def test_unet_vjp_properties_fullsize():
     g1, g2, g12 = m.vjp(c1), m.vjp(c2), m.vjp(0.5 * c1 - 2.0 * c2)
     lin = float((g12 - (0.5 * g1 - 2.0 * g2)).abs().max() / g12.abs().max())
     assert lin < 2e-5, lin
-    v = torch.randn(2, 3, 256, 256, generator=g).cuda()
-    v = v / v.flatten(1).norm(dim=1).view(-1, 1, 1, 1)
-    eps = 2e-2
+    v = torch.randn(2, 3, 256, 256, generator=g).cuda()        # unit variance per element: the step must dominate fp32 noise
+    eps = 5e-3
     fp = m.forward(x + eps * v, t).double()
     fm = m.forward(x - eps * v, t).double()
     lhs = ((fp - fm) / (2 * eps) * c1.double()).flatten(1).sum(1)          # <c, J v> per sample
@@ -139,4 +138,4 @@ def test_unet_vjp_properties_fullsize():
     rhs = (m.vjp(c1).double() * v.double()).flatten(1).sum(1)              # <J^T c, v>
     rel = float(((lhs - rhs).abs() / rhs.abs().clamp_min(1e-6)).max())
     print(f"\nVJP linearity {lin:.1e}; directional derivative rel err {rel:.2e} (lhs {lhs.tolist()}, rhs {rhs.tolist()})")
-    assert rel < 2e-2, (lhs, rhs)
+    assert rel < 5e-3, (lhs, rhs)
