@@ -273,7 +273,7 @@ __device__ __forceinline__ void epilogue_bf16_fast(const ConvParams& p, f32x16 (
 // SUBS = 32-channel sub-chunks staged in LDS per barrier (1 for 3x3; up to 4 for 1x1 so a barrier
 // covers 32 MFMAs per wave instead of 8).
 template <typename T, int NTAPS, int WAVES_M, int WAVES_N, int MT, int NT, int SUBS>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 9) ? (MT * NT == 4 ? KDIP_OCC : (MT * NT == 8 ? 2 : 1)) : 1) void conv_igemm_kernel(ConvParams p) {
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 9) ? (MT * NT == 4 ? KDIP_OCC : (MT * NT == 8 ? 2 : 1)) : ((sizeof(T) == 2 && NTAPS == 1 && MT * NT == 4 && SUBS == 2) ? 3 : 1)) void conv_igemm_kernel(ConvParams p) {
   constexpr int NTHREADS = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * MT * 32;
   constexpr int BN = WAVES_N * NT * 32;
@@ -717,7 +717,10 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
 template <typename T, int NTAPS, int WAVES_M, int WAVES_N, int MT, int NT>
 static int launch_cfg(ConvParams& p, hipStream_t st) {
   if (NTAPS == 1) {
-    // 1x1 / linear: stage up to 128 channels per barrier
+    // 1x1 / linear: stage up to 128 channels per barrier.  The 128x128 tile (big, HBM-bound skip / qkv / proj convs)
+    // does better with 64-channel stages at 3 waves/SIMD (more loads in flight per CU: +20 %); the narrow tiles of the
+    // small-spatial layers keep 128-channel stages (fewer barriers).
+    if (sizeof(T) == 2 && MT * NT == 4 && p.Cin % 64 == 0) return launch_cfg2<T, NTAPS, WAVES_M, WAVES_N, MT, NT, (NTAPS == 1 ? 2 : 1)>(p, st);
     if (KDIP_SUBS1 >= 4 && sizeof(T) == 2 && p.Cin % 128 == 0) return launch_cfg2<T, NTAPS, WAVES_M, WAVES_N, MT, NT, (NTAPS == 1 ? 4 : 1)>(p, st);
     if (KDIP_SUBS1 >= 2 && sizeof(T) == 2 && p.Cin % 64 == 0) return launch_cfg2<T, NTAPS, WAVES_M, WAVES_N, MT, NT, (NTAPS == 1 ? 2 : 1)>(p, st);
   }
