@@ -14,9 +14,12 @@
 //     no LDS round trip, no barrier for weights.
 //   * bf16 storage  -> v_mfma_f32_32x32x16_bf16 (fp32 accumulate);
 //     f32 storage   -> v_mfma_f32_32x32x2_f32  (exact f32, parity mode).
-//   * Epilogue fuses bias, optional residual/accumulate tensor, and the cast.
+//   * Epilogues: bf16 storage -> epilogue_bf16_fast (one branch-free path per {residual} x {no statistics,
+//     GroupNorm forward sums, GroupNorm backward sums}, 16-byte stores); f32 storage / fp32 heads / ragged
+//     Cout -> the generic LDS-transposed or scalar paths.  All fuse alpha, bias, residual and the cast.
 // 64-wide wavefronts; 4 waves/block; XCD-aware block remap keeps all N-tiles of an
-// M-tile on one XCD's L2.
+// M-tile on one XCD's L2.  Build-time knobs (KDIP_*) exist for the A/B and ablation tools in tools/;
+// KDIP_TIMING=1 adds per-block phase stamps (tools/conv_phases.py).
 #include "common.h"
 #include "kernels.h"
 
