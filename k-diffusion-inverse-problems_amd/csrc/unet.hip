@@ -36,35 +36,42 @@ static inline int pad32(int c) { return (c + 31) / 32 * 32; }
 __global__ void linear_f32_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                   const float* __restrict__ bias, int B, int in, int out, int silu_in,
                                   float* __restrict__ y) {
-  // one wave per output feature, all batch rows (8 at a time): the weight row is streamed once instead of B times
-  const int oc = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (oc >= out) return;
-  const float* wr = w + (long)oc * in;
-  const float bv = bias[oc];
-  for (int b0 = 0; b0 < B; b0 += 8) {
-    float s[8];
+  // one wave per 4 output features, 8 batch rows at a time: each weight row is streamed once and every (L2-resident)
+  // input row is re-read by out/4 waves instead of out
+  constexpr int OC = 4, BT = 8;
+  const int oc0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * OC, lane = threadIdx.x & 63;
+  if (oc0 >= out) return;
+  for (int b0 = 0; b0 < B; b0 += BT) {
+    float s[OC][BT];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s[j] = 0.f;
+    for (int o = 0; o < OC; ++o)
+#pragma unroll
+      for (int j = 0; j < BT; ++j) s[o][j] = 0.f;
     for (int i = lane; i < in; i += 64) {
-      const float wv = wr[i];
+      float wv[OC], xv[BT];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if (b0 + j < B) {
-          float xv = x[(long)(b0 + j) * in + i];
-          if (silu_in) xv = xv / (1.f + expf(-xv));
-          s[j] += xv * wv;
-        }
+      for (int o = 0; o < OC; ++o) wv[o] = oc0 + o < out ? w[(long)(oc0 + o) * in + i] : 0.f;
+#pragma unroll
+      for (int j = 0; j < BT; ++j) {
+        xv[j] = b0 + j < B ? x[(long)(b0 + j) * in + i] : 0.f;
+        if (silu_in) xv[j] = xv[j] / (1.f + expf(-xv[j]));
       }
+#pragma unroll
+      for (int o = 0; o < OC; ++o)
+#pragma unroll
+        for (int j = 0; j < BT; ++j) s[o][j] += xv[j] * wv[o];
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float t = wave_sum(s[j]);
-      if (lane == 0 && b0 + j < B) y[(long)(b0 + j) * out + oc] = t + bv;
-    }
+    for (int o = 0; o < OC; ++o)
+#pragma unroll
+      for (int j = 0; j < BT; ++j) {
+        const float t = wave_sum(s[o][j]);
+        if (lane == 0 && oc0 + o < out && b0 + j < B) y[(long)(b0 + j) * out + oc0 + o] = t + bias[oc0 + o];
+      }
   }
 }
 static int linear_f32(hipStream_t st, const float* x, const LinW& L, int B, int silu_in, float* y) {
-  hipLaunchKernelGGL(linear_f32_kernel, dim3(cdiv((long)L.out, 4)), dim3(256), 0, st, x, L.w, L.b, B, L.in, L.out,
+  hipLaunchKernelGGL(linear_f32_kernel, dim3(cdiv((long)L.out, 16)), dim3(256), 0, st, x, L.w, L.b, B, L.in, L.out,
                      silu_in, y);
   KDIP_LAUNCH_CHECK();
   return KDIP_OK;
