@@ -63,6 +63,7 @@ struct ConvParams {
   int cin_real;                   // un-padded input channels (profiling / algorithmic FLOPs only)
   int vec_epilogue;               // LDS-transposed 4-channel-per-lane stores
   int fast_epilogue;              // bf16 out, all strides / pointers 16-byte friendly: 8-channel-per-lane stores (below)
+  int persist;                    // persistent launch: blocks walk a tile range, epilogue LDS sits behind the two A buffers
   // fused GroupNorm statistics of the OUTPUT tensor (vector epilogue, one image per tile only):
   //   st_mode 1: sums[b][g] += (sum y, sum y^2)                         -> next GroupNorm forward
   //   st_mode 2: y is dL/d(GN-apply output); with x = the GN input, z = a*x + b:
@@ -83,7 +84,7 @@ int conv_debug_timing(void* buf, int H, int cin, int cout, int st_mode) {
   return KDIP_OK;
 }
 #if KDIP_TIMING
-#define KDIP_STAMP(i) do { if (p.dbg && threadIdx.x == 0) p.dbg[(long)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#define KDIP_STAMP(i) do { if (p.dbg && threadIdx.x == 0) p.dbg[(long)kdip_tile * 8 + (i)] = wall_clock64(); } while (0)
 #else
 #define KDIP_STAMP(i) do { } while (0)
 #endif
@@ -113,6 +114,11 @@ constexpr int KC = 32;            // input channels per B-pipeline stage (one ta
 #ifndef KDIP_FAST_EPI
 #define KDIP_FAST_EPI 1
 #endif
+#ifndef KDIP_PERSIST
+#define KDIP_PERSIST 0       // 1: persistent 3x3 bf16 launches that stage the next tile's first patch during the last K chunk.
+                             // Correct (full GPU suite passes) but measured 8 % slower end to end: the tile loop costs 88 B of
+                             // scratch at the 168-VGPR budget and the K loop stretches from 18 to 27 us
+#endif
 #ifndef KDIP_EARLY_WRITE
 #define KDIP_EARLY_WRITE 5
 #endif
@@ -136,7 +142,9 @@ constexpr int KC = 32;            // input channels per B-pipeline stage (one ta
 // the residual / GroupNorm-input rows of a whole m-tile are fetched BEFORE the transpose so their
 // HBM latency overlaps the LDS traffic (with the loads inside the store loop, behind uniform
 // branches, every pass paid a full memory round trip: 19-23 us of a 38 us block lifetime).
-template <int WAVES_M, int WAVES_N, int MT, int NT, bool RES, int MODE>
+// ROWS (32 | 16) = height of the per-wave transpose region: 16 halves its LDS footprint (two sub-passes per m-tile) so that
+// it fits behind the two A buffers of a persistent block, whose next patch is already staged when the epilogue runs.
+template <int WAVES_M, int WAVES_N, int MT, int NT, bool RES, int MODE, int ROWS>
 __device__ __forceinline__ void epilogue_bf16_fast(const ConvParams& p, f32x16 (&acc)[MT][NT], unsigned char* smem, int tid,
                                                    int lane, int wave, int wm, int wn, int nt0, int ntb, int img0, int y0,
                                                    int x0) {
@@ -145,8 +153,10 @@ __device__ __forceinline__ void epilogue_bf16_fast(const ConvParams& p, f32x16 (
   constexpr int LPR = NT * 4;                        // lanes (8-channel vectors) per pixel row
   constexpr int RPI = 64 / LPR;                      // pixel rows per pass
   constexpr int NPASS = 32 / RPI;
-  unsigned char* creg = smem + wave * 32 * RS;
-  float* sred = (float*)(smem + WAVES_M * WAVES_N * 32 * RS);     // [BN/4][2] block-level stats combine
+  constexpr int HALVES = 32 / ROWS, PPH = NPASS / HALVES, RPH = 16 / HALVES;   // sub-passes per m-tile, store passes / acc regs each
+  static_assert(PPH * RPI == ROWS, "transpose region height must be a whole number of store passes");
+  unsigned char* creg = smem + wave * ROWS * RS;
+  float* sred = (float*)(smem + WAVES_M * WAVES_N * ROWS * RS);   // [BN/4][2] block-level stats combine
   const int vec = lane % LPR, rowl = lane / LPR;
   const int nl = nt0 * 32 + vec * 8;                 // this lane's 8 output channels
   const int cpg = p.Cout >> 5;
@@ -173,16 +183,20 @@ __device__ __forceinline__ void epilogue_bf16_fast(const ConvParams& p, f32x16 (
       if (RES) rres[it] = *(const uint4*)(res + (long)pix[it] * p.ldr + nl);
     }
 #pragma unroll
+    for (int hf = 0; hf < HALVES; ++hf) {
+#pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      for (int rr = 0; rr < RPH; ++rr) {
+        const int r = hf * RPH + rr;
+        const int row = (r & 3) + 8 * ((r >> 2) - hf * (4 / HALVES)) + 4 * (lane >> 5);
         *(float*)(creg + row * RS + (nt * 32 + (lane & 31)) * 4) = acc[mt][nt][r] * p.alpha + bv[nt];
       }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
-    for (int it = 0; it < NPASS; ++it) {
-      const int row = it * RPI + rowl;
+    for (int it2 = 0; it2 < PPH; ++it2) {
+      const int it = hf * PPH + it2;
+      const int row = it2 * RPI + rowl;
       const float4 v0 = *(const float4*)(creg + row * RS + vec * 32), v1 = *(const float4*)(creg + row * RS + vec * 32 + 16);
       float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
       if (RES) {
@@ -201,6 +215,7 @@ __device__ __forceinline__ void epilogue_bf16_fast(const ConvParams& p, f32x16 (
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
   }
   if (MODE == 2) {
     // GroupNorm-backward sums in a second sweep, once the accumulators are dead (folding it into the store
@@ -293,49 +308,90 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
   constexpr int MAXV = (MAXPIX * VPP + NTHREADS - 1) / NTHREADS;   // staged 16-byte vectors per thread
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
+  constexpr bool PERSIST_K = KDIP_PERSIST && sizeof(T) == 2 && NTAPS == 9 && SUBS == 1;   // instantiations that may run persistently
+  constexpr int EROWS = PERSIST_K ? 16 : 32;           // height of the fast epilogue's per-wave transpose region
+  const int HW_ = p.TW + 2 * HALO, HH_ = p.TH + 2 * HALO;
+  const int npix = p.TB * HH_ * HW_;
+  const int abuf_bytes = npix * PIXB;
+  const int nblkN = (p.ntilesN * 32 + BN - 1) / BN;
+  const int tpi = p.tilesX * p.tilesY;                 // tiles per image (1 when TB>1)
+  const T* xin = (const T*)p.x;
+  // ---- tile walk.  XCD k (= blockIdx % 8) owns a contiguous logical tile range (bijective for any count): all N-tiles of
+  // an M-tile and neighbouring halos stay on one XCD's L2.  Non-persistent launches have one tile per block (the loop runs
+  // once); persistent ones (p.persist) stride through the range, and while the MFMAs of a tile's LAST K chunk run, the first
+  // patch of the block's next tile is staged into the LDS buffer that chunk no longer needs -- the next tile starts without
+  // the load -> LDS -> barrier prologue (3.4 of a 27 us block life).
+  const int ntiles = p.mtiles * nblkN;
+  const int xq = ntiles >> 3, xr = ntiles & 7, xcd = blockIdx.x & 7;
+  const int xstart = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq, xlen = xq + (xcd < xr ? 1 : 0);
+  const int xstride = (gridDim.x + 7) >> 3;
+  int goff[MAXV];                                      // per-thread staging descriptors of the tile being staged: global offset in
+                                                       // 16-byte vectors (-1: zero fill); the LDS slot follows from (tid, i) alone
+  int pb = 0;                                          // LDS buffer holding chunk 0 of the current tile
+  bool have_patch = false;                             // ... already staged by the previous tile's last chunk
+  // (instantiations that never run persistently get a compile-time single trip: no loop-carried state, no hoisting pressure)
+  int xj = blockIdx.x >> 3;
+  if (xj >= xlen) return;
+  do {
+  const int bid = xstart + xj;
+  const int kdip_tile = bid; (void)kdip_tile;
   KDIP_STAMP(0);
-  const int tid = threadIdx.x, lane = tid & 63;
+  // the thread index is re-materialised per tile behind an opaque asm: otherwise every lane-derived address of the
+  // prologue / K loop / epilogues is hoisted out of the tile loop and kept live across it (1 KB of spills)
+  int tid = threadIdx.x;
+  if (PERSIST_K) asm volatile("" : "+v"(tid));
+  const int lane = tid & 63;
   // wave index made provably wave-uniform: everything derived from it (weight-fragment base
   // pointers, LDS regions) then lives in SGPRs and the B loads use the saddr + lane-offset form.
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-
-  // ---- XCD-aware bijective remap: XCD k (= bid % 8) gets a contiguous logical range
-  const int nblk = gridDim.x;
-  int bid = blockIdx.x;
-  {
-    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int nblkN = (p.ntilesN * 32 + BN - 1) / BN;
   const int mtile = bid / nblkN, ntb = bid % nblkN;
   // M tile -> (image group, patch origin)
-  const int tpi = p.tilesX * p.tilesY;                 // tiles per image (1 when TB>1)
   const int img0 = (mtile / tpi) * p.TB;
   const int trem = mtile % tpi;
   const int y0 = (trem / p.tilesX) * p.TH, x0 = (trem % p.tilesX) * p.TW;
-  const int HW_ = p.TW + 2 * HALO, HH_ = p.TH + 2 * HALO;
-  const int npix = p.TB * HH_ * HW_;
-  const int abuf_bytes = npix * PIXB;
+  const bool has_next = xj + xstride < xlen;
+  const bool pref = PERSIST_K && p.persist && has_next;   // stage the next tile's first patch during this tile's last chunk
 
-  // ---- per-thread staging descriptors (constant across K chunks)
-  long goff[MAXV];
-  int loff[MAXV];
-  const T* xin = (const T*)p.x;
+  // staging descriptors of logical tile `tb_` (constant across its K chunks)
+  auto set_offsets = [&](int tb_) {
+    const int mt_ = tb_ / nblkN, im_ = (mt_ / tpi) * p.TB, tr_ = mt_ % tpi;
+    const int yy = (tr_ / p.tilesX) * p.TH, xx = (tr_ % p.tilesX) * p.TW;
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    int v = tid + i * NTHREADS;
-    int pix = v / VPP, sub = v % VPP;
-    goff[i] = -1;
-    loff[i] = -1;
-    if (pix < npix) {
-      // magic reciprocals (exact for the patch sizes used): avoids ~40-instruction integer divisions
-      int tb = (pix * p.magicPatch) >> 20, rr = pix - tb * (HH_ * HW_);
-      int hy = (rr * p.magicRow) >> 20, hx = rr - hy * HW_;
-      int gy = y0 + hy - HALO, gx = x0 + hx - HALO, gb = img0 + tb;
-      loff[i] = pix * PIXB + sub * 16;
-      if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && gb < p.B)
-        goff[i] = (((long)gb * p.H + gy) * p.W + gx) * p.ldx + sub * (16 / (int)sizeof(T));
+    for (int i = 0; i < MAXV; ++i) {
+      int v = tid + i * NTHREADS;
+      int pix = v / VPP, sub = v % VPP;
+      goff[i] = -1;
+      if (pix < npix) {
+        // magic reciprocals (exact for the patch sizes used): avoids ~40-instruction integer divisions
+        int tb = (pix * p.magicPatch) >> 20, rr = pix - tb * (HH_ * HW_);
+        int hy = (rr * p.magicRow) >> 20, hx = rr - hy * HW_;
+        int gy = yy + hy - HALO, gx = xx + hx - HALO, gb = im_ + tb;
+        if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && gb < p.B)
+          goff[i] = (int)(((((long)gb * p.H + gy) * p.W + gx) * p.ldx) / (16 / (int)sizeof(T))) + sub;   // ldx % (16 / sizeof(T)) == 0
+      }
+    }
+  };
+  if (!have_patch) set_offsets(bid);
+  // The next tile's global offsets are worked out HERE, while the accumulators are not live yet, and parked in LDS as 16-byte
+  // vector indices (-1 = zero fill); the last chunk only reads them back.  (Doing the index math inside the K loop pushed the
+  // loop over the 168-VGPR budget: the staging registers themselves were spilled.)
+  int* snext = (int*)(smem + 2 * abuf_bytes + WAVES_M * WAVES_N * EROWS * (NT * 32 * 4 + 16) + BN / 4 * 2 * (int)sizeof(float));
+  if (pref) {
+    const int mt_ = (bid + xstride) / nblkN, im_ = (mt_ / tpi) * p.TB, tr_ = mt_ % tpi;
+    const int yy = (tr_ / p.tilesX) * p.TH, xx = (tr_ % p.tilesX) * p.TW;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int v = tid + i * NTHREADS, pix = v / VPP, sub = v % VPP;
+      int o = -1;
+      if (pix < npix) {
+        int tb = (pix * p.magicPatch) >> 20, rr = pix - tb * (HH_ * HW_);
+        int hy = (rr * p.magicRow) >> 20, hx = rr - hy * HW_;
+        int gy = yy + hy - HALO, gx = xx + hx - HALO, gb = im_ + tb;
+        if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && gb < p.B)
+          o = (int)(((((long)gb * p.H + gy) * p.W + gx) * p.ldx) / (16 / (int)sizeof(T))) + sub;   // ldx % (16 / sizeof(T)) == 0
+      }
+      snext[v] = o;
     }
   }
   // ---- per-lane LDS base offsets of the MT m-tiles this wave owns (tap (0,0))
@@ -378,13 +434,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       areg[i] = make_uint4(0, 0, 0, 0);
-      if (goff[i] >= 0) areg[i] = *(const uint4*)(xin + goff[i] + (long)c * KCH);
+      if (goff[i] >= 0) areg[i] = *(const uint4*)(xin + (long)goff[i] * (16 / (int)sizeof(T)) + (long)c * KCH);
     }
   };
   auto stage_write = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < MAXV; ++i)
-      if (loff[i] >= 0) *(uint4*)(smem + buf * abuf_bytes + loff[i]) = areg[i];
+    {
+      const int v = tid + i * NTHREADS, pix = v / VPP;
+      if (pix < npix) *(uint4*)(smem + buf * abuf_bytes + pix * PIXB + (v % VPP) * 16) = areg[i];
+    }
   };
 
   // B fragments are software-pipelined two stages (= one tap of one 32-channel sub-chunk) ahead in
@@ -403,11 +462,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
 
   // prologue: the first two B stages are requested together with the first patch, ahead of the LDS write + barrier
   // (issued after the barrier their L2 latency sat exposed in front of the first MFMA)
-  stage_load(0);
+  if (!have_patch) stage_load(0);
   load_b(bq0, 0);
   if (KDIP_B_DEPTH == 2) load_b(bq1, 1);
-  stage_write(0);
-  __syncthreads();
+  if (!have_patch) {
+    stage_write(pb);
+    __syncthreads();
+  }
   KDIP_STAMP(1);
 
   // A fragments of the next (sub, tap) stage are read from LDS one stage ahead, so the ds_reads
@@ -420,12 +481,25 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
       for (int mt = 0; mt < MT; ++mt) dst[ks][mt] = *(const uint4*)(abuf + abase[mt] + toff + ks * 32);
   };
   uint4 aq0[KS][MT], aq1[KS][MT];
+  // what the staging slots of chunk c fetch: the next chunk of this tile, or (last chunk of a prefetching tile) chunk 0 of
+  // the block's next tile -- from then on goff describes that tile
+  auto next_load = [&](int c) {
+    if (c + 1 < nchunks) stage_load(c + 1);
+    else if (pref) {
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) {
+        goff[i] = snext[tid + i * NTHREADS];
+      }
+      stage_load(0);
+    }
+  };
   for (int c = 0; c < nchunks; ++c) {
-    const int buf = c & 1;
+    const int buf = (pb + c) & 1;
+    const bool stage_next = c + 1 < nchunks || pref;
     // The loop-carried `s_waitcnt vmcnt(0)` hipcc places before the first MFMA of an iteration would
     // also wait for the (HBM-latency) A-stage loads of the next chunk if they were issued first:
     // issue them after the first stage's MFMAs instead (3x3), so only the old B loads are waited for.
-    if (!KDIP_ABL_NOSTAGE && NTAPS * SUBS == 1 && c + 1 < nchunks) stage_load(c + 1);
+    if (!KDIP_ABL_NOSTAGE && NTAPS * SUBS == 1) next_load(c);
     const unsigned char* abuf = smem + buf * abuf_bytes;
     load_a(aq0, abuf, 0, 0);
 #pragma unroll
@@ -446,10 +520,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) Mma<T>::run(aq0[ks][mt], bq0[ks][nt], acc[mt][nt]);
         if (KDIP_SETPRIO) __builtin_amdgcn_s_setprio(0);
-        if (!KDIP_ABL_NOSTAGE && NTAPS * SUBS > 1 && sub == 0 && tap == 0 && c + 1 < nchunks) stage_load(c + 1);
+        if (!KDIP_ABL_NOSTAGE && NTAPS * SUBS > 1 && sub == 0 && tap == 0) next_load(c);
         // the other LDS buffer was last read in chunk c-1 (all waves are past that barrier), so the next
         // patch can be written mid-chunk: its vmcnt wait and ds_writes leave the end-of-chunk critical path
-        if (!KDIP_ABL_NOSTAGE && EW_AT > 0 && sub * NTAPS + tap == EW_AT && c + 1 < nchunks) stage_write(buf ^ 1);
+        if (!KDIP_ABL_NOSTAGE && EW_AT > 0 && sub * NTAPS + tap == EW_AT && stage_next) stage_write(buf ^ 1);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -470,10 +544,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
       }
     }
     if (!KDIP_ABL_NOSTAGE) {
-      if (EW_AT == 0 && c + 1 < nchunks) stage_write(buf ^ 1);
+      if (EW_AT == 0 && stage_next) stage_write(buf ^ 1);
       __syncthreads();
     }
   }
+  have_patch = pref;
+  pb = (pb + nchunks) & 1;
 
   KDIP_STAMP(2);
   // ---- epilogue: alpha, bias, residual, cast.
@@ -486,11 +562,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
 #pragma unroll
         for (int r = 0; r < 16; ++r) t += acc[mt][nt][r];
     if (t == 12345.678f) ((float*)p.y)[0] = t;
-    return;
+    continue;
   }
   if constexpr (sizeof(T) == 2) {
     if (p.fast_epilogue && (ntb + 1) * BN <= p.Cout) {       // block-uniform
-#define KDIP_EPI(R, M) epilogue_bf16_fast<WAVES_M, WAVES_N, MT, NT, R, M>(p, acc, smem, tid, lane, wave, wm, wn, nt0, ntb, img0, y0, x0)
+      unsigned char* ebase = smem + (p.persist ? 2 * abuf_bytes : 0);   // persistent: behind the A buffers (the next patch is live)
+#define KDIP_EPI(R, M) epilogue_bf16_fast<WAVES_M, WAVES_N, MT, NT, R, M, EROWS>(p, acc, ebase, tid, lane, wave, wm, wn, nt0, ntb, img0, y0, x0)
       if (p.res) {
         if (p.st_mode == 0) KDIP_EPI(true, 0); else if (p.st_mode == 1) KDIP_EPI(true, 1); else KDIP_EPI(true, 2);
       } else {
@@ -498,7 +575,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
       }
 #undef KDIP_EPI
       KDIP_STAMP(3);
-      return;
+      continue;
     }
   }
   const T* res = (const T*)p.res;
@@ -625,7 +702,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
       }
     }
     KDIP_STAMP(3);
-    return;
+    continue;
   }
   // Generic path (ragged Cout, e.g. the 6- and 3-channel heads): MFMA layout, scalar stores.
 #pragma unroll
@@ -650,6 +727,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
       }
     }
   }
+  } while (PERSIST_K && (xj += xstride) < xlen);   // tile loop (`continue` above lands here)
 }
 
 template <typename T, int NTAPS, int WAVES_M, int WAVES_N, int MT, int NT, int SUBS>
@@ -711,6 +789,31 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
       granted = 96 * 1024;
     }
   }
+  // persistent launch (3x3 bf16, every tile on the fast epilogue): (resident blocks per CU) x (CUs) workgroups, a multiple
+  // of 8 (one share per XCD); LDS = two A buffers + the half-height epilogue regions behind them
+  p.persist = 0;
+  if (KDIP_PERSIST && sizeof(T) == 2 && NTAPS == 9 && SUBS == 1 && p.fast_epilogue && p.Cout % BN == 0) {
+    const size_t plds = (size_t)2 * npix * PIXB + (size_t)WAVES_M * WAVES_N * 16 * (NT * 32 * 4 + 16) + (size_t)BN / 4 * 2 * sizeof(float) +
+                        (size_t)((NTAPS == 1 ? BM : 256) * (KC * SUBS * (int)sizeof(T) / 16) + WAVES_M * WAVES_N * 64 - 1) / (WAVES_M * WAVES_N * 64) *
+                            (WAVES_M * WAVES_N * 64) * sizeof(int);                                   // + MAXV x NTHREADS parked offsets
+    static int num_cu = 0, occ = 0;
+    static size_t occ_lds = (size_t)-1;
+    if (!num_cu) {
+      int dev = 0;
+      KDIP_HIP_CHECK(hipGetDevice(&dev));
+      KDIP_HIP_CHECK(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    if (occ_lds != plds) {
+      KDIP_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kern, WAVES_M * WAVES_N * 64, plds));
+      occ_lds = plds;
+    }
+    const long resident = ((long)(occ > 0 ? occ : 1) * num_cu) & ~7L;
+    if (resident >= 8 && grid > resident) {
+      grid = resident;
+      lds = plds;
+      p.persist = 1;
+    }
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES_M * WAVES_N * 64), lds, st, p);
   prof_end(st);
   KDIP_LAUNCH_CHECK();
@@ -763,6 +866,7 @@ int conv_forward(hipStream_t st, DType dt, int ntaps, const void* x, long ldx, i
   KDIP_REQUIRE((ldx * (dt == DT_BF16 ? 2 : 4)) % 16 == 0, "conv: input channel stride must be 16-byte aligned");
   KDIP_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)wp % 16) == 0, "conv: input / packed-weight pointers must be 16-byte aligned");
   KDIP_REQUIRE(B >= 1 && H >= 1 && W >= 1 && Cout >= 1, "conv: empty problem");
+  KDIP_REQUIRE((long)B * H * W * ldx * (dt == DT_BF16 ? 2 : 4) / 16 < (1L << 31), "conv: input tensor too large for 32-bit vector offsets");
   ConvParams p;
   p.x = x; p.ldx = ldx; p.wp = wp; p.bias = bias; p.res = res; p.ldr = ldr; p.y = y; p.ldy = ldy;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.ntilesN = cdiv(Cout, 32);
