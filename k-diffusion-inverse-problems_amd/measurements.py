@@ -364,7 +364,23 @@ class MaskGenerator:
     def __call__(self, img):
         if self.mask_type == 'random':
             return self._retrieve_random(img)
-        raise NotImplementedError(f"mask_type '{self.mask_type}' is outside the hot-path scope (SURVEY.md section 2 row 2)")
+        if self.mask_type in ('box', 'extreme'):
+            mask = self._retrieve_box(img)
+            return 1. - mask if self.mask_type == 'extreme' else mask
+        raise NotImplementedError("mask_type 'both' has no branch in the reference's MaskGenerator.__call__ either (it returns None)")
+
+    def _retrieve_box(self, img):
+        """measurements.py:275-284,300-320: box height then width from np.random.randint(l, h) (global stream), box centred
+        between the margins (the reference's random placement is commented out)."""
+        l, h = int(self.mask_len_range[0]), int(self.mask_len_range[1])
+        mask_h = np.random.randint(l, h)
+        mask_w = np.random.randint(l, h)
+        S = self.image_size
+        t = (self.margin[0] + (S - self.margin[0] - mask_h)) // 2
+        lft = (self.margin[1] + (S - self.margin[1] - mask_w)) // 2
+        mask = torch.ones(img.shape[0], 3, S, S)
+        mask[..., t:t + mask_h, lft:lft + mask_w] = 0
+        return mask
 
     def _retrieve_random(self, img):
         """Draw order pinned to the reference (measurements.py:286-298): one np.random.uniform,

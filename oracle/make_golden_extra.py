@@ -1,8 +1,9 @@
-"""DEV-ONLY: golden trajectory of sample_dpmpp_2m (k_diffusion/sampling.py:583-605) from the real reference.
+"""DEV-ONLY: later additions to the fixtures: sample_dpmpp_2m trajectory (k_diffusion/sampling.py:583-605) and box / extreme
+inpainting masks (condition/measurements.py:264-320), from the real reference.
 
-TEST INFRASTRUCTURE.  Runs only in the build container (needs /root/reference).  Usage: python -m oracle.make_golden_dpmpp2m
+TEST INFRASTRUCTURE.  Runs only in the build container (needs /root/reference).  Usage: python -m oracle.make_golden_extra
 Same tiny model / Gaussian-blur operator / seeds as oracle.make_golden's sampler section; writes
-tests/golden/sampler_dpmpp2m.npz (inputs + expected outputs) after asserting reference == oracle.
+tests/golden/sampler_dpmpp2m.npz and tests/golden/masks_box.npz (inputs + expected outputs) after asserting reference == oracle.
 """
 import os
 import sys
@@ -42,6 +43,21 @@ def main():
     np.savez_compressed(os.path.join(GOLD, "sampler_dpmpp2m.npz"), sigmas=sig.numpy(), xT=xT.numpy(), x0=x_r.detach().numpy(),
                         denoised_first=trace_r[0].numpy(), denoised_last=trace_r[-1].numpy(), y=meas_r[0].numpy(), y_flat=meas_r[1].numpy())
     print("written", os.path.join(GOLD, "sampler_dpmpp2m.npz"))
+
+    # ---- box / extreme masks: numpy seed -> mask bits (bit-exact contract, like the random mask)
+    dump = {}
+    for mt in ("box", "extreme"):
+        for seed, S_, rng_ in ((0, 256, (128, 129)), (5, 256, (64, 160)), (7, 64, (16, 40))):
+            opt = dict(mask_type=mt, mask_len_range=rng_, image_size=S_)
+            with refimport.reference_cwd():
+                np.random.seed(seed)
+                r = cm.get_operator("inpainting", device="cpu", sigma_s=0.05, mask_opt=opt)
+            np.random.seed(seed)
+            o = oops.get_operator("inpainting", sigma_s=0.05, mask_opt=opt)
+            assert torch.equal(r.mask, o.mask), (mt, seed)
+            dump[f"{mt}|{seed}|{S_}|{rng_[0]}|{rng_[1]}"] = np.packbits(r.mask[0, 0].numpy().astype(np.uint8))
+    np.savez_compressed(os.path.join(GOLD, "masks_box.npz"), **dump)
+    print("written", os.path.join(GOLD, "masks_box.npz"), len(dump), "masks")
 
 
 if __name__ == "__main__":

@@ -135,6 +135,22 @@ def random_mask(image_size, prob_range, rng=np.random):
     return mask_b[None].clone()
 
 
+def box_mask(image_size, len_range, margin=(16, 16), extreme=False, rng=np.random):
+    """MaskGenerator._retrieve_box + _random_sq_bbox (measurements.py:275-320): two randint(l, h) draws (height, then width)
+    from the global numpy stream, box CENTRED between the margins (the random placement is commented out in the
+    reference); 'extreme' = complement.  Returns float32 [1,3,S,S] in {0,1}."""
+    l, h = int(len_range[0]), int(len_range[1])
+    mask_h = rng.randint(l, h)
+    mask_w = rng.randint(l, h)
+    maxt = image_size - margin[0] - mask_h
+    maxl = image_size - margin[1] - mask_w
+    t = (margin[0] + maxt) // 2
+    lft = (margin[1] + maxl) // 2
+    mask = torch.ones([1, 3, image_size, image_size])
+    mask[..., t:t + mask_h, lft:lft + mask_w] = 0
+    return 1.0 - mask if extreme else mask
+
+
 # -------------------------------------------------------------- operators ----
 class _Blur:
     def __init__(self, in_shape, sigma_s, psf_name):
@@ -218,8 +234,12 @@ class Inpainting:
         size = mask_opt["image_size"]
         self.in_shape = (1, 3, size, size)
         if mask is None:
-            assert mask_opt["mask_type"] == "random"
-            mask = random_mask(size, mask_opt["mask_prob_range"])
+            mt = mask_opt["mask_type"]
+            if mt == "random":
+                mask = random_mask(size, mask_opt["mask_prob_range"])
+            else:
+                assert mt in ("box", "extreme"), mt
+                mask = box_mask(size, mask_opt["mask_len_range"], mask_opt.get("margin", (16, 16)), extreme=(mt == "extreme"))
         self.mask = mask
         self.pre_calculated = None
 

@@ -235,7 +235,7 @@ def test_harness_config_loaders(tmp_path):
     exec(compile(src[src.index("def load_yaml"):src.index("def folder_of_images")], "loaders", "exec"), {"yaml": __import__("yaml"), "json": __import__("json")}, ns)
     t = ns["load_yaml"](os.path.join(root, "configs", "tasks.yaml#gaussian_deblur"))
     assert t == {"name": "gaussian_blur", "in_shape": [1, 3, 256, 256], "kernel_size": 61, "intensity": 3.0, "sigma_s": 0.05}
-    assert set(ns["load_yaml"](os.path.join(root, "configs", "tasks.yaml"))) == {"gaussian_deblur", "motion_deblur", "super_resolution_4x", "inpainting"}
+    assert set(ns["load_yaml"](os.path.join(root, "configs", "tasks.yaml"))) == {"gaussian_deblur", "motion_deblur", "super_resolution_4x", "inpainting", "inpainting_box"}
     m = ns["load_json"](os.path.join(root, "configs", "models.json#imagenet"))
     assert m["model"]["openai"] == {"num_channels": 256, "num_res_blocks": 2, "attention_resolutions": "8,16,32"}
     f = tmp_path / "one.yaml"

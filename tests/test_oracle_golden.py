@@ -223,3 +223,22 @@ def test_sampler_dpmpp2m_trajectory(gold):
     x = osamp.sample_dpmpp_2m(m, T(g["xT"]).clone(), T(g["sigmas"]), callback=lambda d: first.append(d["denoised"]))
     assert float((first[0] - T(g["denoised_first"])).abs().max()) < 5e-4
     assert float((x - T(g["x0"])).abs().max()) < 5e-4
+
+
+def test_box_masks_bit_exact(gold):
+    """box / extreme inpainting masks (measurements.py:264-320): numpy seed -> identical bits, oracle and host generator."""
+    import numpy as np
+    import kdip_amd.measurements as km
+    from oracle import operators as oops
+    g = gold("masks_box")
+    assert len(g.files) == 6
+    for key in g.files:
+        mt, seed, S, lo, hi = key.split("|")
+        seed, S, lo, hi = int(seed), int(S), int(lo), int(hi)
+        want = np.unpackbits(g[key]).reshape(S, S).astype(np.float32)
+        np.random.seed(seed)
+        o = oops.box_mask(S, (lo, hi), extreme=(mt == "extreme"))
+        assert np.array_equal(o[0, 0].numpy(), want) and np.array_equal(o[0, 2].numpy(), want), key
+        np.random.seed(seed)
+        h = km.MaskGenerator(mask_type=mt, mask_len_range=(lo, hi), image_size=S)(torch.empty(1, 3, S, S))
+        assert h.shape == (1, 3, S, S) and np.array_equal(h[0, 1].numpy(), want), key

@@ -291,6 +291,33 @@ def test_shared_measurement_broadcast(gold, tiny, name, guidance, cov, kw):
         mk((y.repeat(2, 1, 1, 1), yf.repeat(2, 1)))(xs, sig)
 
 
+def test_box_inpainting_vs_oracle(gold, tiny):
+    """Box-mask inpainting (mask_type 'box', the centred box of measurements.py:300-320): operator, flatten / transpose paths
+    and a Type-I + Convert guided call (CG branch) against the oracle."""
+    import numpy as np
+    import kdip_amd.condition as kc
+    import kdip_amd.measurements as km
+    from oracle import operators as oops, condition as ocond
+    models, D, sd, cfg = tiny
+    opt = dict(mask_type="box", mask_len_range=(20, 36), image_size=64)
+    np.random.seed(3); hop = km.get_operator("inpainting", device="cuda", sigma_s=0.05, mask_opt=opt)
+    np.random.seed(3); oop = oops.get_operator("inpainting", sigma_s=0.05, mask_opt=opt)
+    assert torch.equal(hop.mask.cpu(), oop.mask)
+    x0 = T(gold("operators")["x0"])
+    torch.manual_seed(2); y_o, yf_o = oop.forward(x0.clone(), flatten=True)
+    y_h = hop.forward(x0.cuda(), noiseless=True)
+    assert float((y_h.cpu() - oop.forward(x0.clone(), noiseless=True)).abs().max()) < 1e-6
+    at = hop.transpose(yf_o.cuda(), flatten=True)
+    assert float((at.cpu() - oop.transpose(yf_o, flatten=True)).abs().max()) < 1e-6
+    x = x0 + 0.12 * torch.randn(1, 3, 64, 64, generator=torch.Generator().manual_seed(11))
+    sig = torch.tensor([0.12])
+    ref = ocond.GuidedDenoiser(sd, cfg, oop, (y_o, yf_o), "I", x0_cov_type="convert")(x, sig)
+    m = kc.ConditionOpenAIDenoiser(inner_model=models["f32"], diffusion=D, x0_cov_type="convert", recon_mse=None, operator=hop,
+                                   measurement=(y_o.cuda(), yf_o.cuda()), guidance="I", device="cuda")
+    hat = m(x.cuda(), sig.cuda()).cpu()
+    assert float((hat - ref).abs().max()) < 1e-3
+
+
 def test_error_behaviour(gold, tiny):
     import kdip_amd.condition as kc
     import kdip_amd.measurements as km
