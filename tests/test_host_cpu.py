@@ -94,8 +94,10 @@ def test_mask_generator_bit_exact(gold):
     bits = np.unpackbits(g["inpainting.mask256_bits"]).reshape(256, 256)
     assert np.array_equal(m[0, 0].numpy().astype(np.uint8), bits)
     assert torch.equal(m[0, 0], m[0, 1]) and torch.equal(m[0, 0], m[0, 2])
+    box = km.MaskGenerator(mask_type="box", mask_len_range=(128, 129))(torch.empty(1, 3, 256, 256))     # centred 128 x 128 box
+    assert float(box.sum()) == 3 * (256 * 256 - 128 * 128) and float(box[0, 0, 64:192, 64:192].sum()) == 0
     with pytest.raises(NotImplementedError):
-        km.MaskGenerator(mask_type="box", mask_len_range=(128, 129))(torch.empty(1, 3, 256, 256))
+        km.MaskGenerator(mask_type="both", mask_len_range=(128, 129), mask_prob_range=(0.5, 0.5))(torch.empty(1, 3, 256, 256))
 
 
 def test_resize_tables_match_oracle():
