@@ -1,5 +1,5 @@
 """GPU: the caller harness (sample_condition.py, the stand-in for sample_condition_openai.py) end to end on synthetic
-weights / data: every operator config parses, a short sampler run writes args.yaml, avg_metrics.yaml and PNGs."""
+weights / data: every task entry of configs/tasks.yaml parses, a short sampler run writes args.yaml, avg_metrics.yaml and PNGs."""
 import os
 import subprocess
 import sys
@@ -17,6 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ("inpainting", ["--config", "configs/models.json#ffhq_dct", "--guidance", "II", "--spatial-var"]),
     ("inpainting", ["--guidance", "dps", "--xstart-cov-type", "dps", "--zeta", "1.0", "--euler", "--ode"]),
     ("super_resolution_4x", ["--guidance", "II", "--xstart-cov-type", "pgdm"]),
+    ("inpainting_box", ["--guidance", "dps+mle", "--xstart-cov-type", "convert", "--zeta", "1.0", "--ode"]),
     ("motion_deblur", ["--guidance", "I", "--xstart-cov-type", "analytic", "--ode"]),
 ])
 def test_harness_runs(tmp_path, op, extra):
