@@ -63,6 +63,7 @@ struct ConvParams {
   int cin_real;                   // un-padded input channels (profiling / algorithmic FLOPs only)
   int vec_epilogue;               // LDS-transposed 4-channel-per-lane stores
   int fast_epilogue;              // bf16 out, all strides / pointers 16-byte friendly: 8-channel-per-lane stores (below)
+  int in_ups, res_ups;            // input / residual are half-resolution tensors read at (y >> 1, x >> 1) (fused nearest x2 upsample)
   int persist;                    // persistent launch: blocks walk a tile range, epilogue LDS sits behind the two A buffers
   // fused GroupNorm statistics of the OUTPUT tensor (vector epilogue, one image per tile only):
   //   st_mode 1: sums[b][g] += (sum y, sum y^2)                         -> next GroupNorm forward
@@ -180,7 +181,10 @@ __device__ __forceinline__ void epilogue_bf16_fast(const ConvParams& p, f32x16 (
       const int tb = m >> p.lgTHW, rr = m & ((1 << p.lgTHW) - 1);
       const int ty = rr >> p.lgTW, tx = rr & (p.TW - 1);
       pix[it] = ((img0 + tb) * p.H + (y0 + ty)) * p.W + (x0 + tx);
-      if (RES) rres[it] = *(const uint4*)(res + (long)pix[it] * p.ldr + nl);
+      if (RES) {
+        const int rp = p.res_ups ? ((img0 + tb) * (p.H >> 1) + ((y0 + ty) >> 1)) * (p.W >> 1) + ((x0 + tx) >> 1) : pix[it];
+        rres[it] = *(const uint4*)(res + (long)rp * p.ldr + nl);
+      }
     }
 #pragma unroll
     for (int hf = 0; hf < HALVES; ++hf) {
@@ -367,8 +371,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
         int tb = (pix * p.magicPatch) >> 20, rr = pix - tb * (HH_ * HW_);
         int hy = (rr * p.magicRow) >> 20, hx = rr - hy * HW_;
         int gy = yy + hy - HALO, gx = xx + hx - HALO, gb = im_ + tb;
-        if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && gb < p.B)
-          goff[i] = (int)(((((long)gb * p.H + gy) * p.W + gx) * p.ldx) / (16 / (int)sizeof(T))) + sub;   // ldx % (16 / sizeof(T)) == 0
+        if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && gb < p.B) {
+          const long spix = p.in_ups ? ((long)gb * (p.H >> 1) + (gy >> 1)) * (p.W >> 1) + (gx >> 1) : ((long)gb * p.H + gy) * p.W + gx;
+          goff[i] = (int)((spix * p.ldx) / (16 / (int)sizeof(T))) + sub;   // ldx % (16 / sizeof(T)) == 0
+        }
       }
     }
   };
@@ -388,8 +394,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
         int tb = (pix * p.magicPatch) >> 20, rr = pix - tb * (HH_ * HW_);
         int hy = (rr * p.magicRow) >> 20, hx = rr - hy * HW_;
         int gy = yy + hy - HALO, gx = xx + hx - HALO, gb = im_ + tb;
-        if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && gb < p.B)
-          o = (int)(((((long)gb * p.H + gy) * p.W + gx) * p.ldx) / (16 / (int)sizeof(T))) + sub;   // ldx % (16 / sizeof(T)) == 0
+        if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && gb < p.B) {
+          const long spix = p.in_ups ? ((long)gb * (p.H >> 1) + (gy >> 1)) * (p.W >> 1) + (gx >> 1) : ((long)gb * p.H + gy) * p.W + gx;
+          o = (int)((spix * p.ldx) / (16 / (int)sizeof(T))) + sub;   // ldx % (16 / sizeof(T)) == 0
+        }
       }
       snext[v] = o;
     }
@@ -628,13 +636,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
         float4 v = *(const float4*)(creg + row * RS + vec * 16);
         if (gb < p.B && n < p.Cout) {
           const long pix = ((long)gb * p.H + (y0 + ty)) * p.W + (x0 + tx);
+          const long rpix = p.res_ups ? ((long)gb * (p.H >> 1) + ((y0 + ty) >> 1)) * (p.W >> 1) + ((x0 + tx) >> 1) : pix;
           if (res) {
             if (sizeof(T) == 2) {
-              uint2 rv = *(const uint2*)(res + pix * p.ldr + n);
+              uint2 rv = *(const uint2*)(res + rpix * p.ldr + n);
               v.x += __uint_as_float(rv.x << 16); v.y += __uint_as_float(rv.x & 0xffff0000u);
               v.z += __uint_as_float(rv.y << 16); v.w += __uint_as_float(rv.y & 0xffff0000u);
             } else {
-              float4 rv = *(const float4*)(res + pix * p.ldr + n);
+              float4 rv = *(const float4*)(res + rpix * p.ldr + n);
               v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
             }
           }
@@ -721,7 +730,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
         if (!nok || gb >= p.B) continue;
         long pix = ((long)gb * p.H + (y0 + ty)) * p.W + (x0 + tx);
         float v = acc[mt][nt][r] * p.alpha + bv;
-        if (res) v += to_f32(res[pix * p.ldr + n]);
+        if (res) {
+          const long rpix = p.res_ups ? ((long)gb * (p.H >> 1) + ((y0 + ty) >> 1)) * (p.W >> 1) + ((x0 + tx) >> 1) : pix;
+          v += to_f32(res[rpix * p.ldr + n]);
+        }
         if (p.out_f32) ((float*)p.y)[pix * p.ldy + n] = v;
         else ((T*)p.y)[pix * p.ldy + n] = from_f32<T>(v);
       }
@@ -872,6 +884,8 @@ int conv_forward(hipStream_t st, DType dt, int ntaps, const void* x, long ldx, i
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.ntilesN = cdiv(Cout, 32);
   p.out_f32 = out_f32; p.alpha = alpha; p.cin_real = cin_real > 0 ? cin_real : Cin;
   p.st_mode = 0; p.st_silu = 0; p.st_sums = nullptr; p.st_x = nullptr; p.st_ldx = 0; p.st_coef = nullptr; p.st_mr = nullptr;
+  p.in_ups = stt ? stt->in_ups : 0; p.res_ups = stt ? stt->res_ups : 0;
+  KDIP_REQUIRE(!(p.in_ups || p.res_ups) || (H % 2 == 0 && W % 2 == 0), "conv: fused x2 upsample needs even H, W");
   if (stt && stt->mode) {
     p.st_mode = stt->mode; p.st_silu = stt->silu; p.st_sums = stt->sums; p.st_x = stt->x; p.st_ldx = stt->ldx;
     p.st_coef = stt->coef; p.st_mr = stt->mr;

@@ -55,90 +55,6 @@ int avgpool2(hipStream_t st, DType dt, const void* x, long ldx, int B, int H, in
   return KDIP_OK;
 }
 
-template <typename T>
-__global__ void upsample2_kernel(const T* __restrict__ x, long ldx, int B, int H, int W, int VP, T* __restrict__ y,
-                                 long ldy) {
-  constexpr int EPV = TypeInfo<T>::EPV;
-  const int Ho = H * 2, Wo = W * 2;
-  long nvec = (long)B * Ho * Wo * VP;
-  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (long)gridDim.x * blockDim.x) {
-    int vi = (int)(v % VP);
-    long op = v / VP;
-    int ox = (int)(op % Wo);
-    long t = op / Wo;
-    int oy = (int)(t % Ho), b = (int)(t / Ho);
-    uint4 val = *(const uint4*)(x + (((long)b * H + oy / 2) * W + ox / 2) * ldx + (long)vi * EPV);
-    *(uint4*)(y + op * ldy + (long)vi * EPV) = val;
-  }
-}
-
-int upsample2(hipStream_t st, DType dt, const void* x, long ldx, int B, int H, int W, int C, void* y, long ldy) {
-  int VP = C / (dt == DT_BF16 ? 8 : 4);
-  long nvec = (long)B * (H * 2) * (W * 2) * VP;
-  if (dt == DT_BF16)
-    hipLaunchKernelGGL(upsample2_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const bf16_t*)x, ldx, B, H, W, VP,
-                       (bf16_t*)y, ldy);
-  else
-    hipLaunchKernelGGL(upsample2_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const float*)x, ldx, B, H, W, VP,
-                       (float*)y, ldy);
-  KDIP_LAUNCH_CHECK();
-  return KDIP_OK;
-}
-
-// ------------------------------------------------------------------- copies / adds ----
-template <typename T>
-__global__ void copy_channels_kernel(const T* __restrict__ x, long ldx, long nvec, int VP, T* __restrict__ y, long ldy) {
-  constexpr int EPV = TypeInfo<T>::EPV;
-  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (long)gridDim.x * blockDim.x) {
-    long pix = v / VP;
-    int vi = (int)(v % VP);
-    *(uint4*)(y + pix * ldy + (long)vi * EPV) = *(const uint4*)(x + pix * ldx + (long)vi * EPV);
-  }
-}
-
-int copy_channels(hipStream_t st, DType dt, const void* x, long ldx, long npix, int C, void* y, long ldy) {
-  int VP = C / (dt == DT_BF16 ? 8 : 4);
-  long nvec = npix * VP;
-  if (dt == DT_BF16)
-    hipLaunchKernelGGL(copy_channels_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const bf16_t*)x, ldx, nvec, VP,
-                       (bf16_t*)y, ldy);
-  else
-    hipLaunchKernelGGL(copy_channels_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const float*)x, ldx, nvec, VP,
-                       (float*)y, ldy);
-  KDIP_LAUNCH_CHECK();
-  return KDIP_OK;
-}
-
-template <typename T>
-__global__ void add_channels_kernel(const T* __restrict__ a, long lda, const T* __restrict__ b, long ldb, long nvec,
-                                    int VP, T* __restrict__ y, long ldy) {
-  constexpr int EPV = TypeInfo<T>::EPV;
-  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (long)gridDim.x * blockDim.x) {
-    long pix = v / VP;
-    int vi = (int)(v % VP);
-    float fa[EPV], fb[EPV];
-    unpack16<T>(*(const uint4*)(a + pix * lda + (long)vi * EPV), fa);
-    unpack16<T>(*(const uint4*)(b + pix * ldb + (long)vi * EPV), fb);
-#pragma unroll
-    for (int e = 0; e < EPV; ++e) fa[e] += fb[e];
-    *(uint4*)(y + pix * ldy + (long)vi * EPV) = pack16<T>(fa);
-  }
-}
-
-int add_channels(hipStream_t st, DType dt, const void* a, long lda, const void* b, long ldb, long npix, int C, void* y,
-                 long ldy) {
-  int VP = C / (dt == DT_BF16 ? 8 : 4);
-  long nvec = npix * VP;
-  if (dt == DT_BF16)
-    hipLaunchKernelGGL(add_channels_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const bf16_t*)a, lda,
-                       (const bf16_t*)b, ldb, nvec, VP, (bf16_t*)y, ldy);
-  else
-    hipLaunchKernelGGL(add_channels_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const float*)a, lda,
-                       (const float*)b, ldb, nvec, VP, (float*)y, ldy);
-  KDIP_LAUNCH_CHECK();
-  return KDIP_OK;
-}
-
 // ------------------------------------------------------------------------- softmax ----
 // One wavefront per row (cols <= 4096); fp32 math as in `th.softmax(weight.float())`.
 template <typename T>

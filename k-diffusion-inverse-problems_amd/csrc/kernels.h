@@ -11,6 +11,9 @@ struct ConvStats {
   double* sums = nullptr;          // [B][32][2], pre-zeroed by the caller
   const void* x = nullptr; long ldx = 0;
   const float* coef = nullptr; const float* mr = nullptr;
+  // nearest-neighbour x2 upsampling folded into the reads (Upsample of an upsampling ResBlock, unet.py:232-235): the input
+  // tensor / the residual tensor are HALF-resolution [B, H/2, W/2, C] and pixel (y, x) reads (y >> 1, x >> 1)
+  int in_ups = 0, res_ups = 0;
 };
 // true iff conv_forward can fuse statistics for an output of this shape
 inline bool conv_stats_eligible(int H, int W, int Cout) { return (long)H * W >= 128 && Cout % 128 == 0; }
@@ -69,11 +72,7 @@ int gn_bwd_small(hipStream_t st, DType dt, const void* x, long ldx, const void* 
 
 // ---- elementwise.hip --------------------------------------------------------------------
 int avgpool2(hipStream_t st, DType dt, const void* x, long ldx, int B, int H, int W, int C, void* y, long ldy, float scale);
-int upsample2(hipStream_t st, DType dt, const void* x, long ldx, int B, int H, int W, int C, void* y, long ldy);
 // sum of each 2x2 block (adjoint of nearest upsample): implemented as avgpool2 with scale 4.
-int copy_channels(hipStream_t st, DType dt, const void* x, long ldx, long npix, int C, void* y, long ldy);
-int add_channels(hipStream_t st, DType dt, const void* a, long lda, const void* b, long ldb, long npix, int C,
-                 void* y, long ldy);
 int softmax_rows(hipStream_t st, DType dt, const float* s, long rows, int cols, void* p);
 // dS = P * (dP - rowsum(dP*P)); dP fp32 in, P dtype T, dS out dtype T
 int softmax_bwd_rows(hipStream_t st, DType dt, const void* p, const float* dp, long rows, int cols, void* ds);

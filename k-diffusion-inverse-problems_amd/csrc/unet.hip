@@ -320,17 +320,19 @@ int gn_backward(Ctx& c, const void* x, long ldx, const void* dy, long lddy, cons
   return KDIP_OK;
 }
 
+// in_ups / res_ups: x / res are half-resolution tensors read through a fused nearest x2 upsample (H, W = output size)
 int conv_f(Ctx& c, const ConvW& w, const void* x, long ldx, int B, int H, int W, void* y, long ldy, const void* res,
-           long ldr, int out_f32, bool fuse_out_stats = false) {
+           long ldr, int out_f32, bool fuse_out_stats = false, int in_ups = 0, int res_ups = 0) {
   bool dry = c.dry;
   ConvStats stt;
+  stt.in_ups = in_ups; stt.res_ups = res_ups;
   if (fuse_out_stats && !out_f32 && conv_stats_eligible(H, W, w.cout) && !gn_small_eligible(c.dt, (long)H * W, w.cout)) {
     stt.mode = 1;
     stt.sums = new_sums(c, B);
     c.u->fused_stats[std::make_pair((const void*)y, w.cout)] = stt.sums;
   }
   RUN(conv_forward(c.st, c.dt, w.ntaps, x, ldx, B, H, W, w.cin_pad, w.wf, w.bias, w.cout, y, ldy, res, ldr, out_f32, 1.f, w.cin,
-                   stt.mode ? &stt : nullptr));
+                   (stt.mode || in_ups || res_ups) ? &stt : nullptr));
   return KDIP_OK;
 }
 // input-gradient: x here is dL/d(out) with >= cin_pad_b channels available (zero padded when cout % 32 != 0)
@@ -400,7 +402,7 @@ static int res_forward(Ctx& c, Layer& L, const void* x, long ldx, int B, int& H,
   void* h1 = fused_pool ? nullptr : u->scratch.alloc(es * B * HW * L.cin);
   if (!fused_pool) CK(gn_forward(c, x, ldx, B, HW, L.n1, nullptr, 1, h1, L.cin, &L.sv.coef1, &L.sv.mr1));
   const void* cin_ptr = h1; const void* xs = x; long ldxs = ldx;
-  int Ho = H, Wo = W;
+  int Ho = H, Wo = W, ups = 0;
   if (L.mode == 1) {
     Ho = H / 2; Wo = W / 2;
     void* h1p = u->scratch.alloc(es * B * Ho * Wo * L.cin);
@@ -413,28 +415,26 @@ static int res_forward(Ctx& c, Layer& L, const void* x, long ldx, int B, int& H,
     }
     cin_ptr = h1p; xs = xp; ldxs = L.cin;
   } else if (L.mode == 2) {
+    // Upsample(use_conv=False) of both branches (unet.py:232-235) is folded into the consumers' reads: conv1 and the skip
+    // path read the half-resolution tensors at (y >> 1, x >> 1); no 4x-sized copies are written or re-read
     Ho = H * 2; Wo = W * 2;
-    void* h1p = u->scratch.alloc(es * B * Ho * Wo * L.cin);
-    void* xp = u->scratch.alloc(es * B * Ho * Wo * L.cin);
-    RUN(upsample2(c.st, c.dt, h1, L.cin, B, H, W, L.cin, h1p, L.cin));
-    RUN(upsample2(c.st, c.dt, x, ldx, B, H, W, L.cin, xp, L.cin));
-    cin_ptr = h1p; xs = xp; ldxs = L.cin;
+    ups = 1;
   }
   const long HWo = (long)Ho * Wo;
   void* h2 = u->persist.alloc(es * B * HWo * L.cout);
   L.sv.h2 = h2;
-  CK(conv_f(c, L.c1, cin_ptr, L.cin, B, Ho, Wo, h2, L.cout, nullptr, 0, 0, true));
+  CK(conv_f(c, L.c1, cin_ptr, L.cin, B, Ho, Wo, h2, L.cout, nullptr, 0, 0, true, ups, 0));
   const float* film = film_all + L.emb_off;          // row b at film + b * emb_total
   void* h3 = u->scratch.alloc(es * B * HWo * L.cout);
   CK(gn_forward(c, h2, L.cout, B, HWo, L.n2, film, 1, h3, L.cout, &L.sv.coef2, &L.sv.mr2, u->emb_total));
   const void* S = xs; long ldS = ldxs;
   if (L.has_skip) {
     void* sk = u->scratch.alloc(es * B * HWo * L.cout);
-    CK(conv_f(c, L.skip, xs, ldxs, B, Ho, Wo, sk, L.cout, nullptr, 0, 0));
+    CK(conv_f(c, L.skip, xs, ldxs, B, Ho, Wo, sk, L.cout, nullptr, 0, 0, false, ups, 0));
     S = sk; ldS = L.cout;
   }
   void* o = dst ? dst : u->persist.alloc(es * B * HWo * L.cout);
-  CK(conv_f(c, L.c2, h3, L.cout, B, Ho, Wo, o, dst ? ldd : L.cout, S, ldS, 0, true));
+  CK(conv_f(c, L.c2, h3, L.cout, B, Ho, Wo, o, dst ? ldd : L.cout, S, ldS, 0, true, 0, (ups && !L.has_skip) ? 1 : 0));
   *outp = o; H = Ho; W = Wo;
   return KDIP_OK;
 }
