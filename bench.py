@@ -156,33 +156,19 @@ def main():
     full_run = args.steps % 100 == 0 and args.steps > 0
     idx = step_indices(args.steps)
 
-    def run_part(pt, steps, chain, res, k):
-        try:
-            torch.cuda.set_device(dev)
-            with torch.cuda.stream(pt["stream"]):
-                x = start_state(pt, 0)
-                for i in steps:
-                    if not chain or i == 0:
-                        x = start_state(pt, i)
-                    x = ks.heun_step(pt["den"], x, sig, i)
-                res[k] = x
-        except BaseException as e:          # re-raised by the caller
-            res[k] = e
+    def run_part(pt, steps, chain):
+        x = start_state(pt, 0)
+        for i in steps:
+            if not chain or i == 0:
+                x = start_state(pt, i)
+            x = ks.heun_step(pt["den"], x, sig, i)
+        return x
 
     def run_all(steps, chain):
-        res = [None] * S_
-        if S_ == 1:
-            run_part(parts[0], steps, chain, res, 0)
-        else:
-            import threading
-            th = [threading.Thread(target=run_part, args=(parts[k], steps, chain, res, k)) for k in range(S_)]
-            for t in th: t.start()
-            for t in th: t.join()
-        for r in res:
-            if isinstance(r, BaseException):
-                raise r
+        from kdip_amd.evaluation import run_on_streams
+        outs = run_on_streams([lambda pt=pt: run_part(pt, steps, chain) for pt in parts], [pt["stream"] for pt in parts], dev)
         torch.cuda.synchronize()
-        return torch.cat(res)
+        return torch.cat(outs)
 
     # ---- warm-up: one closed-form step and one CG step per warm-up pair (allocates the workspaces)
     if args.warmup > 0:

@@ -90,3 +90,37 @@ def psnr(hat_x0, x0):
     b = (x0 / 2 + 0.5).clip(0, 1)
     mse = ((a - b) ** 2).flatten(1).mean(dim=1)
     return 10 * torch.log10(1.0 / mse)
+
+
+def run_on_streams(fns, streams=None, device=None):
+    """Run the callables `fns[k]()` concurrently, each inside its own HIP stream context on its own host thread, and return
+    their results in order (exceptions are re-raised).  Independent part-batches driven this way overlap one part's
+    HBM-bound passes and host-side convergence waits with another part's MFMA-bound convs (bench.py --streams,
+    sample_condition.py --streams).  Every callable must use its own UNet handle and operator context: library handles
+    are per (thread, stream), never shared."""
+    import threading
+    n = len(fns)
+    if n == 1:
+        return [fns[0]()]
+    device = device if device is not None else torch.cuda.current_device()
+    streams = streams or [torch.cuda.Stream(device=device) for _ in range(n)]
+    res = [None] * n
+
+    def work(k):
+        try:
+            torch.cuda.set_device(device)
+            with torch.cuda.stream(streams[k]):
+                res[k] = fns[k]()
+        except BaseException as e:
+            res[k] = e
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(n)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for r in res:
+        if isinstance(r, BaseException):
+            raise r
+    torch.cuda.synchronize(device)
+    return res

@@ -113,6 +113,8 @@ def main():
     p.add_argument("--synthetic-weights", action="store_true", help="seeded random-init weights when the checkpoint is absent")
     p.add_argument("--synthetic-data", type=int, default=0, metavar="N", help="N seeded smooth images when the dataset folder is absent")
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--streams", type=int, default=1, help="split each sampler batch into this many part-batches, each with its own "
+                   "UNet handle / operator context / HIP stream / host thread (overlaps HBM-bound and MFMA-bound phases)")
     args = p.parse_args()
 
     config = load_json(args.config)
@@ -128,7 +130,9 @@ def main():
     if env.is_main_process:
         print("Using device:", device, flush=True)
 
-    inner_model, diffusion = ku.create_model_and_diffusion(image_size=size[0], dtype=args.dtype, device=device, **model_config["openai"])
+    nstreams = max(1, args.streams)
+    models = [ku.create_model_and_diffusion(image_size=size[0], dtype=args.dtype, device=device, **model_config["openai"]) for _ in range(nstreams)]
+    inner_model, diffusion = models[0]
     if os.path.exists(args.checkpoint):
         sd = ku.normalize_state_dict(torch.load(args.checkpoint, map_location="cpu"))   # plain .pt or Lightning .ckpt layout
     elif args.synthetic_weights:
@@ -137,7 +141,8 @@ def main():
                                      attention_resolutions=model_config["openai"]["attention_resolutions"])
     else:
         raise FileNotFoundError(f"checkpoint {args.checkpoint} not found (pass --synthetic-weights for random-init weights)")
-    inner_model.load_state_dict(sd)
+    for m, _ in models:
+        m.load_state_dict(sd)
     sigma_min, sigma_max = model_config["sigma_min"], model_config["sigma_max"]
 
     if os.path.isdir(dataset_config["location"]):
@@ -148,7 +153,13 @@ def main():
         raise FileNotFoundError(f"dataset folder {dataset_config['location']} not found (pass --synthetic-data N)")
 
     operator_config = load_yaml(args.operator_config)
-    operator = km.get_operator(device=device, **operator_config)
+    import numpy as np
+    rng_state = np.random.get_state()
+    operators = []
+    for _ in range(nstreams):                      # identical operators (same mask draw), one device context per stream
+        np.random.set_state(rng_state)
+        operators.append(km.get_operator(device=device, **operator_config))
+    operator = operators[0]
     if env.is_main_process:
         print(f"Operation: {operator_config['name']} / sigma_s: {operator_config['sigma_s']}")
         os.makedirs(args.logdir, exist_ok=True)
@@ -169,25 +180,36 @@ def main():
     for i, x0 in enumerate(images):
         x0 = x0[None].to(device)
         measurement = operator.forward(x0.clone(), flatten=True)
-        if v2:
-            from kdip_amd.external import OpenAIDenoiserV2
-            denoiser = OpenAIDenoiserV2(inner_model, diffusion, device=device, ortho_tf_type=model_config.get("ortho_tf_type"))
-            model = kc.ConditionOpenAIDenoiserV2(
-                denoiser=denoiser, operator=operator, measurement=measurement, guidance=args.guidance, device=device, zeta=args.zeta,
-                lambda_=args.lam, eta=args.eta, num_hutchinson_samples=args.num_hutchinson_samples, mle_sigma_thres=args.mle_sigma_thres,
-                ortho_tf_type=None if args.spatial_var else model_config.get("ortho_tf_type"))
-        else:
-            model = kc.ConditionOpenAIDenoiser(
-                inner_model=inner_model, diffusion=diffusion, operator=operator, measurement=measurement, guidance=args.guidance,
+        def make_model(k):
+            if v2:
+                from kdip_amd.external import OpenAIDenoiserV2
+                denoiser = OpenAIDenoiserV2(models[k][0], diffusion, device=device, ortho_tf_type=model_config.get("ortho_tf_type"))
+                return kc.ConditionOpenAIDenoiserV2(
+                    denoiser=denoiser, operator=operators[k], measurement=measurement, guidance=args.guidance, device=device, zeta=args.zeta,
+                    lambda_=args.lam, eta=args.eta, num_hutchinson_samples=args.num_hutchinson_samples, mle_sigma_thres=args.mle_sigma_thres,
+                    ortho_tf_type=None if args.spatial_var else model_config.get("ortho_tf_type"))
+            return kc.ConditionOpenAIDenoiser(
+                inner_model=models[k][0], diffusion=diffusion, operator=operators[k], measurement=measurement, guidance=args.guidance,
                 x0_cov_type=args.xstart_cov_type, recon_mse=recon_mse, lambda_=args.lam, zeta=args.zeta, eta=args.eta,
                 num_hutchinson_samples=args.num_hutchinson_samples, mle_sigma_thres=args.mle_sigma_thres, device=device)
 
-        def sample_fn(n):
-            x = torch.randn([n, model_config["input_channels"], size[0], size[1]], device=device) * sigma_max
+        cond_models = [make_model(k) for k in range(nstreams)]
+
+        def sample_part(model, x):
             sampler = partial(ks.sample_heun if not args.euler else ks.sample_euler, model, x, sigmas, disable=True)
             if not args.ode:
                 return sampler(s_churn=80, s_tmin=0.05, s_tmax=50, s_noise=1.003)
             return sampler()
+
+        def sample_fn(n):
+            x = torch.randn([n, model_config["input_channels"], size[0], size[1]], device=device) * sigma_max
+            k = min(nstreams, n)
+            if k == 1:
+                return sample_part(cond_models[0], x)
+            torch.cuda.synchronize()
+            chunks = x.chunk(k)
+            outs = ke.run_on_streams([lambda m=cond_models[j], c=chunks[j]: sample_part(m, c.contiguous()) for j in range(len(chunks))], device=device)
+            return torch.cat(outs)
 
         hat_x0 = ke.compute_features(env, sample_fn, lambda x: x, args.n, args.batch_size)
         metrics = kmet.compute_metrics(hat_x0, x0)
