@@ -1,12 +1,13 @@
 #!/usr/bin/env python
 """Benchmark of the hot path: BASELINE.json configs[1] -- FFHQ 256x256 Gaussian deblur, Type-I
-guidance with Convert posterior covariance, 100 Heun steps, batch 128 per MI355X (--batch) run as
---streams (2) independent part-batches on their own HIP streams / host threads.
+guidance with Convert posterior covariance, 100 Heun steps, batch 16 per MI355X (--batch) run as
+--streams (2) independent part-batches on their own HIP streams / host threads.  At N = 1 the same run is
+repeated at batch 128 and reported as `throughput_at_batch_128` (per-image cost falls with batch).
 
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one Heun sampler step of the 100-step Karras schedule over one batch of 128 synthetic
+A "step" is one Heun sampler step of the 100-step Karras schedule over one batch of 16 synthetic
 images (2 guided-denoiser calls = 2 UNet forwards + 2 hand-written UNet VJPs + 2 mat-solves, CG
 on the sigma < 0.2 steps).  With K = 100 (default) the timed region is the whole sampler run; with
 K < 100 the K timed steps are spread evenly over the schedule (so the closed-form / CG mix is
@@ -106,7 +107,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=128, help="images per GPU")
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU (BASELINE configs[1]: 16)")
+    ap.add_argument("--no-large-batch", action="store_true", help="skip the extra throughput leg at batch 128 (N = 1 only)")
     ap.add_argument("--streams", type=int, default=2, help="part-batches per GPU, each on its own HIP stream + host thread")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -126,35 +128,35 @@ def main():
     B, S, rank = args.batch, 256, env.rank
     lib = L.load()
 
-    # ---- the per-GPU batch is split into `--streams` part-batches, each with its own UNet handle (weights + workspace),
-    # operator context, HIP stream and host thread: images are independent problems, so while one part is in its
-    # HBM-bound GroupNorm passes or waits for a CG convergence flag, the other part's convs have the MFMA pipes.
-    S_ = max(1, min(args.streams, B))
     D = ku.GaussianDiffusionTables()
     sigmas = ks.get_sigmas_karras(100, 0.01, 80, rho=7.0, device=dev)
     sig = sigmas.detach().cpu()
     sd = ku.synthetic_state_dict(seed=0, **ku.FFHQ_CONFIG)      # random-init weights of the named architecture (no checkpoint offline)
-    parts = []
-    for k in range(S_):
-        Bk = B // S_ + (1 if k < B % S_ else 0)
-        model = ku.UNetModel(dtype="bf16", device=dev, **ku.FFHQ_CONFIG)
-        model.load_state_dict(sd)
-        # operator + synthetic measurement (sigma_s = 0.05), rank- and part-offset seeds: every image is its own problem
-        op = km.get_operator("gaussian_blur", device=dev, in_shape=(1, 3, S, S), kernel_size=61, intensity=3.0, sigma_s=0.05)
-        x0 = smooth_image(Bk, S, seed=1 + 1000 * rank + 100 * k).to(dev)
-        torch.manual_seed(2 + 1000 * rank + 100 * k)
-        meas = op.forward(x0.clone(), flatten=True)
-        den = kc.ConditionOpenAIDenoiser(inner_model=model, diffusion=D, x0_cov_type="convert", recon_mse=None, operator=op,
-                                         measurement=meas, guidance="I", mle_sigma_thres=0.2, device=dev).eval()
-        noise = torch.randn(Bk, 3, S, S, device=dev, generator=torch.Generator(device=dev).manual_seed(3 + 1000 * rank + 100 * k))
-        parts.append(dict(den=den, x0=x0, noise=noise, stream=torch.cuda.Stream(device=dev) if S_ > 1 else torch.cuda.current_stream(), B=Bk))
-    torch.cuda.synchronize()
+
+    # ---- the per-GPU batch is split into `--streams` part-batches, each with its own UNet handle (weights + workspace),
+    # operator context, HIP stream and host thread: images are independent problems, so while one part is in its
+    # HBM-bound GroupNorm passes or waits for a CG convergence flag, the other part's convs have the MFMA pipes.
+    def build_parts(Btot, nstreams):
+        nstreams = max(1, min(nstreams, Btot))
+        parts = []
+        for k in range(nstreams):
+            Bk = Btot // nstreams + (1 if k < Btot % nstreams else 0)
+            model = ku.UNetModel(dtype="bf16", device=dev, **ku.FFHQ_CONFIG)
+            model.load_state_dict(sd)
+            # operator + synthetic measurement (sigma_s = 0.05), rank- and part-offset seeds: every image is its own problem
+            op = km.get_operator("gaussian_blur", device=dev, in_shape=(1, 3, S, S), kernel_size=61, intensity=3.0, sigma_s=0.05)
+            x0 = smooth_image(Bk, S, seed=1 + 1000 * rank + 100 * k).to(dev)
+            torch.manual_seed(2 + 1000 * rank + 100 * k)
+            meas = op.forward(x0.clone(), flatten=True)
+            den = kc.ConditionOpenAIDenoiser(inner_model=model, diffusion=D, x0_cov_type="convert", recon_mse=None, operator=op,
+                                             measurement=meas, guidance="I", mle_sigma_thres=0.2, device=dev).eval()
+            noise = torch.randn(Bk, 3, S, S, device=dev, generator=torch.Generator(device=dev).manual_seed(3 + 1000 * rank + 100 * k))
+            parts.append(dict(den=den, x0=x0, noise=noise, stream=torch.cuda.Stream(device=dev) if nstreams > 1 else torch.cuda.current_stream(), B=Bk))
+        torch.cuda.synchronize()
+        return parts
 
     def start_state(pt, i):
         return (pt["x0"] + float(sig[i]) * pt["noise"]).contiguous() if i > 0 else (pt["noise"] * float(sig[0])).contiguous()
-
-    full_run = args.steps % 100 == 0 and args.steps > 0
-    idx = step_indices(args.steps)
 
     def run_part(pt, steps, chain):
         x = start_state(pt, 0)
@@ -164,27 +166,34 @@ def main():
             x = ks.heun_step(pt["den"], x, sig, i)
         return x
 
-    def run_all(steps, chain):
+    def run_all(parts, steps, chain):
         from kdip_amd.evaluation import run_on_streams
         outs = run_on_streams([lambda pt=pt: run_part(pt, steps, chain) for pt in parts], [pt["stream"] for pt in parts], dev)
         torch.cuda.synchronize()
         return torch.cat(outs)
 
-    # ---- warm-up: one closed-form step and one CG step per warm-up pair (allocates the workspaces)
-    if args.warmup > 0:
-        run_all([10 if w % 2 == 0 else 95 for w in range(args.warmup)], False)
-    torch.cuda.synchronize()
+    def timed_run(parts, steps, chain, warmup):
+        """warm-up (one closed-form and one CG step per pair: allocates the workspaces), then barrier-bracketed timing incl. the
+        one collective of the path (RCCL all_gather); returns max-over-ranks seconds."""
+        if warmup > 0:
+            run_all(parts, [10 if w % 2 == 0 else 95 for w in range(warmup)], False)
+        torch.cuda.synchronize()
+        env.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        x = run_all(parts, steps, chain)
+        hat = env.gather(x)
+        torch.cuda.synchronize()
+        env.barrier()
+        elapsed = env.max_over_ranks(time.perf_counter() - t0)
+        assert torch.isfinite(hat).all()
+        return elapsed
 
-    # ---- timed region
-    env.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    x = run_all(idx, full_run)
-    hat = env.gather(x)                                   # the one collective of the path (RCCL all_gather)
-    torch.cuda.synchronize()
-    env.barrier()
-    elapsed = env.max_over_ranks(time.perf_counter() - t0)
-    assert torch.isfinite(hat).all()
+    full_run = args.steps % 100 == 0 and args.steps > 0
+    idx = step_indices(args.steps)
+    parts = build_parts(B, args.streams)
+    S_ = len(parts)
+    elapsed = timed_run(parts, idx, full_run, args.warmup)
     den, x0 = parts[0]["den"], parts[0]["x0"]             # the roofline leg profiles part 0 alone
 
     ms_per_step = elapsed / args.steps * 1e3
@@ -250,6 +259,23 @@ def main():
                                   for j in range(n) if la[j] > 0 and not names[j].startswith("conv")},
         }
         L.check(lib.kdip_profile_enable(0))
+
+    # ---- extra leg (N = 1, default workload only): the same sampler run at the throughput-optimal batch.  BASELINE configs[1]
+    # fixes the batch at 16 images per GPU (that is `value`); per-image cost keeps falling until ~128 images per GPU.  Run as a
+    # fresh process (this one is idle meanwhile): re-using this process after its own workspaces were freed measured 6 % slower.
+    if not args.no_large_batch and env.world_size == 1 and full_run and B == 16:
+        import subprocess
+        del parts, den, x0
+        torch.cuda.empty_cache()
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--batch", "128", "--streams", str(args.streams), "--steps", str(args.steps),
+                                "--warmup", "2", "--no-cpu-baseline", "--no-roofline", "--no-large-batch"], capture_output=True, text=True, timeout=900)
+            big = json.loads(r.stdout.strip().splitlines()[-1])
+            out["throughput_at_batch_128"] = {"value": big["value"], "unit": "images/s", "per_gpu_batch": 128,
+                                              "streams_per_gpu": big["config"]["streams_per_gpu"], "ms_per_step": big["ms_per_step"],
+                                              "note": "same code path and timing protocol (python bench.py --batch 128), 128 images per GPU instead of the 16 of BASELINE configs[1]"}
+        except Exception as e:            # the headline measurement above must survive a failure of the optional leg
+            out["throughput_at_batch_128"] = {"error": repr(e)[:200]}
 
     # ---- CPU baseline (rank 0, single-GPU runs only; bounded sample)
     if not args.no_cpu_baseline and env.is_main_process and env.world_size == 1:

@@ -4,7 +4,7 @@ coalesced reads; WRITE_SIZE (KiB) as reported (it matched the algorithmic write 
 usage: python tools/pmc_to_json.py <batch>"""
 import csv, glob, json, os, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 64     # per-launch batch (bench batch 128 over 2 streams)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8     # per-launch batch (bench batch 16 over 2 streams)
 KERNEL = "conv_igemm_kernel<unsigned short, 9, 2, 2, 2, 2, 1>"
 vals = collections.defaultdict(list)
 durs = []
