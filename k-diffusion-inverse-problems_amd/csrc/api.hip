@@ -192,7 +192,7 @@ int kdip_test_conv(void* stream, int dtype, int ntaps, const float* x_nchw, int 
   const int cpad = pad32i(Ci);
   std::vector<char> buf(packed_weight_bytes(dt, ntaps, cpad, Co));
   pack_conv_weight(dt, w_host, Cout, Cin, ntaps, transpose_flip, cpad, buf.data());
-  void *wp = nullptr, *xin = nullptr, *ys = nullptr; float *bias = nullptr, *y32 = nullptr;
+  void *wp = nullptr, *xin = nullptr, *ys = nullptr; float *bias = nullptr, *y32 = nullptr, *skws = nullptr;
   KDIP_HIP_CHECK(hipMalloc(&wp, buf.size()));
   KDIP_HIP_CHECK(hipMemcpy(wp, buf.data(), buf.size(), hipMemcpyHostToDevice));
   if (bias_host) { KDIP_HIP_CHECK(hipMalloc((void**)&bias, sizeof(float) * Co)); KDIP_HIP_CHECK(hipMemcpy(bias, bias_host, sizeof(float) * Co, hipMemcpyHostToDevice)); }
@@ -201,7 +201,10 @@ int kdip_test_conv(void* stream, int dtype, int ntaps, const float* x_nchw, int 
   int rc = nchw_to_nhwc(st, dt, x_nchw, B, Ci, H, W, 1.f, xin, cpad, cpad);
   if (storage_out) {     // the UNet-internal epilogues: output in the storage dtype
     KDIP_HIP_CHECK(hipMalloc(&ys, es * (size_t)B * H * W * opad));
-    if (!rc) rc = conv_forward(st, dt, ntaps, xin, cpad, B, H, W, cpad, wp, bias, Co, ys, opad, nullptr, 0, 0, 1.f);
+    const long wsf = (long)B * H * W * Co;             // zeroed split-K workspace: under-filled shapes take the split-K path
+    KDIP_HIP_CHECK(hipMalloc((void**)&skws, sizeof(float) * wsf));
+    KDIP_HIP_CHECK(hipMemsetAsync(skws, 0, sizeof(float) * wsf, st));
+    if (!rc) rc = conv_forward(st, dt, ntaps, xin, cpad, B, H, W, cpad, wp, bias, Co, ys, opad, nullptr, 0, 0, 1.f, 0, nullptr, skws, wsf);
     if (!rc) rc = nhwc_T_to_nchw_f32(st, dt, ys, opad, B, Co, H, W, y_nchw);
   } else {               // the fp32-output epilogue of the output heads / final input gradient
     KDIP_HIP_CHECK(hipMalloc((void**)&y32, sizeof(float) * (size_t)B * H * W * opad));
@@ -209,7 +212,7 @@ int kdip_test_conv(void* stream, int dtype, int ntaps, const float* x_nchw, int 
     if (!rc) rc = nhwc_to_nchw_f32(st, y32, opad, B, Co, H, W, y_nchw);
   }
   hipError_t e = hipStreamSynchronize(st);
-  (void)hipFree(wp); (void)hipFree(xin); if (y32) (void)hipFree(y32); if (ys) (void)hipFree(ys); if (bias) (void)hipFree(bias);
+  (void)hipFree(wp); (void)hipFree(xin); if (y32) (void)hipFree(y32); if (ys) (void)hipFree(ys); if (skws) (void)hipFree(skws); if (bias) (void)hipFree(bias);
   if (rc) return rc;
   KDIP_HIP_CHECK(e);
   return KDIP_OK;

@@ -63,6 +63,8 @@ struct ConvParams {
   int cin_real;                   // un-padded input channels (profiling / algorithmic FLOPs only)
   int vec_epilogue;               // LDS-transposed 4-channel-per-lane stores
   int fast_epilogue;              // bf16 out, all strides / pointers 16-byte friendly: 8-channel-per-lane stores (below)
+  float* sk_ws; long sk_ws_floats; int sk_splits;    // split-K (small-spatial layers): blockIdx.y owns a K-chunk range, fp32 partial sums are
+                                  // atomically added to sk_ws [B*H*W][Cout] (zero on entry; conv_splitk_finalize re-zeroes it)
   int in_ups, res_ups;            // input / residual are half-resolution tensors read at (y >> 1, x >> 1) (fused nearest x2 upsample)
   int persist;                    // persistent launch: blocks walk a tile range, epilogue LDS sits behind the two A buffers
   // fused GroupNorm statistics of the OUTPUT tensor (vector epilogue, one image per tile only):
@@ -119,6 +121,12 @@ constexpr int KC = 32;            // input channels per B-pipeline stage (one ta
 #define KDIP_PERSIST 0       // 1: persistent 3x3 bf16 launches that stage the next tile's first patch during the last K chunk.
                              // Correct (full GPU suite passes) but measured 8 % slower end to end: the tile loop costs 88 B of
                              // scratch at the 168-VGPR budget and the K loop stretches from 18 to 27 us
+#endif
+#ifndef KDIP_SPLITK
+#define KDIP_SPLITK 1
+#endif
+#ifndef KDIP_SPLITK_FILL
+#define KDIP_SPLITK_FILL 512   // split K until a launch has about this many blocks (2 per CU)
 #endif
 #ifndef KDIP_EARLY_WRITE
 #define KDIP_EARLY_WRITE 5
@@ -436,7 +444,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-  const int nchunks = p.Cin / KCH;
+  const int nchunks_all = p.Cin / KCH;
+  // split-K: this block's chunk range [c_begin, c_end); one range = everything otherwise
+  const int c_begin = p.sk_splits > 1 ? (int)((long)nchunks_all * blockIdx.y / p.sk_splits) : 0;
+  const int nchunks = p.sk_splits > 1 ? (int)((long)nchunks_all * (blockIdx.y + 1) / p.sk_splits) : nchunks_all;   // = c_end
   uint4 areg[MAXV];
   auto stage_load = [&](int c) {
 #pragma unroll
@@ -457,7 +468,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
   // B fragments are software-pipelined two stages (= one tap of one 32-channel sub-chunk) ahead in
   // registers; a stage index past the end is clamped to the last stage (one redundant L2 hit) so the
   // loop body has no branches.
-  const int nstages = nchunks * SUBS * NTAPS;
+  const int nstages = nchunks_all * SUBS * NTAPS;
   auto load_b = [&](uint4 (&dst)[KS][NT], int stage) {
     stage = stage < nstages ? stage : nstages - 1;
     const int c32 = stage / NTAPS, tp = stage - c32 * NTAPS;
@@ -470,9 +481,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
 
   // prologue: the first two B stages are requested together with the first patch, ahead of the LDS write + barrier
   // (issued after the barrier their L2 latency sat exposed in front of the first MFMA)
-  if (!have_patch) stage_load(0);
-  load_b(bq0, 0);
-  if (KDIP_B_DEPTH == 2) load_b(bq1, 1);
+  if (!have_patch) stage_load(c_begin);
+  load_b(bq0, c_begin * SUBS * NTAPS);
+  if (KDIP_B_DEPTH == 2) load_b(bq1, c_begin * SUBS * NTAPS + 1);
   if (!have_patch) {
     stage_write(pb);
     __syncthreads();
@@ -501,8 +512,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
       stage_load(0);
     }
   };
-  for (int c = 0; c < nchunks; ++c) {
-    const int buf = (pb + c) & 1;
+  for (int c = c_begin; c < nchunks; ++c) {
+    const int buf = (pb + c - c_begin) & 1;
     const bool stage_next = c + 1 < nchunks || pref;
     // The loop-carried `s_waitcnt vmcnt(0)` hipcc places before the first MFMA of an iteration would
     // also wait for the (HBM-latency) A-stage loads of the next chunk if they were issued first:
@@ -557,7 +568,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
     }
   }
   have_patch = pref;
-  pb = (pb + nchunks) & 1;
+  pb = (pb + nchunks - c_begin) & 1;
 
   KDIP_STAMP(2);
   // ---- epilogue: alpha, bias, residual, cast.
@@ -570,6 +581,26 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
 #pragma unroll
         for (int r = 0; r < 16; ++r) t += acc[mt][nt][r];
     if (t == 12345.678f) ((float*)p.y)[0] = t;
+    continue;
+  }
+  if (p.sk_splits > 1) {
+    // split-K partial sums: fp32 atomics into the zeroed workspace; bias / residual / cast happen in conv_splitk_finalize
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = (nt0 + nt) * 32 + (lane & 31);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const int tb = m >> p.lgTHW, rr = m & ((1 << p.lgTHW) - 1);
+          const int ty = rr >> p.lgTW, tx = rr & (p.TW - 1);
+          const int gb = img0 + tb;
+          if (n < p.Cout && gb < p.B)
+            atomicAdd(p.sk_ws + (((long)gb * p.H + (y0 + ty)) * p.W + (x0 + tx)) * p.Cout + n, acc[mt][nt][r] * p.alpha);
+        }
+    }
+    KDIP_STAMP(3);
     continue;
   }
   if constexpr (sizeof(T) == 2) {
@@ -742,6 +773,26 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
   } while (PERSIST_K && (xj += xstride) < xlen);   // tile loop (`continue` above lands here)
 }
 
+// y = T(ws + bias (+ res)); ws is zeroed again for the next split-K launch
+template <typename T>
+__global__ void conv_splitk_finalize_kernel(float* __restrict__ ws, const float* __restrict__ bias, const T* __restrict__ res, long ldr,
+                                            long npix, int Cout, T* __restrict__ y, long ldy) {
+  const long n4 = (long)Cout / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix * n4; i += (long)gridDim.x * blockDim.x) {
+    const long pix = i / n4;
+    const int c = (int)(i % n4) * 4;
+    float4 v = *(float4*)(ws + pix * Cout + c);
+    *(float4*)(ws + pix * Cout + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+    float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (bias) f[e] += bias[c + e];
+      if (res) f[e] += to_f32(res[pix * ldr + c + e]);
+      y[pix * ldy + c + e] = from_f32<T>(f[e]);
+    }
+  }
+}
+
 template <typename T, int NTAPS, int WAVES_M, int WAVES_N, int MT, int NT, int SUBS>
 static int launch_cfg2(ConvParams& p, hipStream_t st) {
   constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32;
@@ -826,7 +877,25 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
       p.persist = 1;
     }
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES_M * WAVES_N * 64), lds, st, p);
+  // split-K for under-filled launches (small-spatial layers: a few dozen tiles, hundreds of K chunks each)
+  int splits = 1;
+  {
+    const int nchunks = p.Cin / (KC * SUBS);
+    // (3x3 only: on the short-K 1x1 convs the atomics + finalize pass cost more than the extra blocks bring, measured)
+    if (KDIP_SPLITK && NTAPS == 9 && p.sk_ws && (long)p.B * p.H * p.W * p.Cout <= p.sk_ws_floats && !p.persist && !p.st_mode && !p.out_f32 && !p.res_ups && p.Cout % 4 == 0 && grid * 2 <= KDIP_SPLITK_FILL && nchunks >= 4) {
+      splits = (int)(KDIP_SPLITK_FILL / grid);
+      if (splits > nchunks / 2) splits = nchunks / 2;
+      if (splits > 16) splits = 16;
+    }
+  }
+  p.sk_splits = splits;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)splits), dim3(WAVES_M * WAVES_N * 64), lds, st, p);
+  if (splits > 1) {
+    const long npix = (long)p.B * p.H * p.W;
+    long g = (npix * (p.Cout / 4) + 255) / 256; if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(conv_splitk_finalize_kernel<T>, dim3((unsigned)g), dim3(256), 0, st, p.sk_ws, p.bias, (const T*)p.res, p.ldr, npix, p.Cout,
+                       (T*)p.y, p.ldy);
+  }
   prof_end(st);
   KDIP_LAUNCH_CHECK();
   return KDIP_OK;
@@ -872,7 +941,7 @@ static int launch_T(ConvParams& p, hipStream_t st) {
 
 int conv_forward(hipStream_t st, DType dt, int ntaps, const void* x, long ldx, int B, int H, int W, int Cin,
                  const void* wp, const float* bias, int Cout, void* y, long ldy, const void* res, long ldr,
-                 int out_f32, float alpha, int cin_real, const ConvStats* stt) {
+                 int out_f32, float alpha, int cin_real, const ConvStats* stt, float* sk_ws, long sk_ws_floats) {
   KDIP_REQUIRE(Cin % KC == 0, "conv: Cin=%d must be a multiple of %d (pad the input)", Cin, KC);
   KDIP_REQUIRE(ntaps == 9 || ntaps == 1, "conv: ntaps must be 9 or 1");
   KDIP_REQUIRE((ldx * (dt == DT_BF16 ? 2 : 4)) % 16 == 0, "conv: input channel stride must be 16-byte aligned");
@@ -885,6 +954,7 @@ int conv_forward(hipStream_t st, DType dt, int ntaps, const void* x, long ldx, i
   p.out_f32 = out_f32; p.alpha = alpha; p.cin_real = cin_real > 0 ? cin_real : Cin;
   p.st_mode = 0; p.st_silu = 0; p.st_sums = nullptr; p.st_x = nullptr; p.st_ldx = 0; p.st_coef = nullptr; p.st_mr = nullptr;
   p.in_ups = stt ? stt->in_ups : 0; p.res_ups = stt ? stt->res_ups : 0;
+  p.sk_ws = sk_ws; p.sk_ws_floats = sk_ws_floats; p.sk_splits = 1;
   KDIP_REQUIRE(!(p.in_ups || p.res_ups) || (H % 2 == 0 && W % 2 == 0), "conv: fused x2 upsample needs even H, W");
   if (stt && stt->mode) {
     p.st_mode = stt->mode; p.st_silu = stt->silu; p.st_sums = stt->sums; p.st_x = stt->x; p.st_ldx = stt->ldx;

@@ -19,7 +19,9 @@ struct ConvStats {
 inline bool conv_stats_eligible(int H, int W, int Cout) { return (long)H * W >= 128 && Cout % 128 == 0; }
 int conv_forward(hipStream_t st, DType dt, int ntaps, const void* x, long ldx, int B, int H, int W, int Cin,
                  const void* wp, const float* bias, int Cout, void* y, long ldy, const void* res, long ldr,
-                 int out_f32, float alpha, int cin_real = 0, const ConvStats* stt = nullptr);
+                 int out_f32, float alpha, int cin_real = 0, const ConvStats* stt = nullptr, float* sk_ws = nullptr, long sk_ws_floats = 0);
+// sk_ws: optional fp32 split-K workspace of sk_ws_floats floats, all zero on entry and on return; when given, under-filled
+// launches (small-spatial layers) split their K range over blockIdx.y and reduce through it
 size_t packed_weight_bytes(DType dt, int ntaps, int Cin_pad, int Cout);
 int conv_debug_timing(void* buf, int H, int cin, int cout, int st_mode);   // -DKDIP_TIMING=1 diagnostic builds only
 void pack_conv_weight(DType dt, const float* w, int Cout, int Cin, int ntaps, int transpose_flip, int Cin_pad_out,

@@ -332,7 +332,7 @@ int conv_f(Ctx& c, const ConvW& w, const void* x, long ldx, int B, int H, int W,
     c.u->fused_stats[std::make_pair((const void*)y, w.cout)] = stt.sums;
   }
   RUN(conv_forward(c.st, c.dt, w.ntaps, x, ldx, B, H, W, w.cin_pad, w.wf, w.bias, w.cout, y, ldy, res, ldr, out_f32, 1.f, w.cin,
-                   (stt.mode || in_ups || res_ups) ? &stt : nullptr));
+                   (stt.mode || in_ups || res_ups) ? &stt : nullptr, c.u->sk_ws, c.u->sk_ws_floats));
   return KDIP_OK;
 }
 // input-gradient: x here is dL/d(out) with >= cin_pad_b channels available (zero padded when cout % 32 != 0)
@@ -350,7 +350,7 @@ int conv_b(Ctx& c, const ConvW& w, const void* g, long ldg, int B, int H, int W,
     *sums_out = stt.sums;
   }
   RUN(conv_forward(c.st, c.dt, w.ntaps, g, ldg, B, H, W, w.cin_pad_b, w.wb, nullptr, w.cin, y, ldy, res, ldr, out_f32, 1.f, w.cout,
-                   stt.mode ? &stt : nullptr));
+                   stt.mode ? &stt : nullptr, c.u->sk_ws, c.u->sk_ws_floats));
   return KDIP_OK;
 }
 }  // namespace
@@ -490,6 +490,16 @@ int UNet::forward_impl(hipStream_t st, const float* x_nchw, const float* t, int 
   const size_t es = esize();
   persist.reset(); scratch.reset(); zeros.reset(); fused_stats.clear();
   if (!dry && zeros.cap) KDIP_HIP_CHECK(hipMemsetAsync(zeros.base, 0, zeros.cap, st));
+  {
+    // split-K workspace: room for any conv output on a <= 16x16 map (the layers whose launches cannot fill the chip)
+    int maxc = 0;
+    auto upd = [&](const std::vector<Layer>& ls) { for (auto& L : ls) { maxc = std::max(maxc, std::max(L.cin, L.cout)); if (L.kind == 2) maxc = std::max(maxc, 3 * L.cin); } };
+    for (auto& b : inp) upd(b);
+    upd(mid);
+    for (auto& b : out) upd(b);
+    sk_ws_floats = (long)B * 256 * maxc;
+    sk_ws = (float*)zeros.alloc(sizeof(float) * sk_ws_floats);
+  }
   int H = cfg.image_size, W = cfg.image_size;
   const int mc = cfg.model_channels, ted = mc * 4;
   // timestep embedding MLP (fp32)

@@ -40,6 +40,9 @@ CONV_CASES = [
     (2, 64, 256, 256, 256, 1),
     (32, 64, 128, 64, 64, 9),
     (4, 96, 256, 256, 256, 9),     # full-resolution layer shape: 3 K-chunks, two N tiles, 2048 blocks
+    (2, 512, 256, 8, 8, 9),        # small map, long K: split-K (storage-dtype epilogue) -- 8 tiles x 8 K ranges
+    (8, 384, 512, 16, 16, 9),      # split-K with uneven chunk ranges (12 chunks over 4-5 splits)
+    (4, 512, 128, 8, 8, 1),        # small-map 1x1 (stays un-split)
 ]
 
 
