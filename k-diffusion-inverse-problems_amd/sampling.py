@@ -55,9 +55,10 @@ def _trange(n, disable):
         return range(n)
 
 
-def _churn(x, sig, i, s_churn, s_tmin, s_tmax, s_noise, lib):
+def _churn(x, sig, i, s_churn, s_tmin, s_tmax, s_noise, lib, noise_fn=None):
     gamma = min(s_churn / (len(sig) - 1), 2 ** 0.5 - 1) if s_tmin <= sig[i] <= s_tmax else 0.
-    eps = torch.randn_like(x)
+    # noise_fn(x) -> eps: lets a caller inject pre-drawn noise (e.g. the reference's CPU stream) instead of the device RNG
+    eps = torch.randn_like(x) if noise_fn is None else noise_fn(x).to(x.device, x.dtype).contiguous()
     sigma_hat = sig[i] * (gamma + 1)
     if gamma > 0:
         scale = float((sigma_hat ** 2 - sig[i] ** 2) ** 0.5) * float(s_noise)
@@ -68,13 +69,13 @@ def _churn(x, sig, i, s_churn, s_tmin, s_tmax, s_noise, lib):
 
 
 def sample_euler(model, x, sigmas, extra_args=None, callback=None, disable=None, s_churn=0., s_tmin=0.,
-                 s_tmax=float('inf'), s_noise=1.):
+                 s_tmax=float('inf'), s_noise=1., noise_fn=None):
     """Algorithm 2 (Euler steps) from Karras et al. (2022)."""
     extra_args = {} if extra_args is None else extra_args
     lib = L.load()
     x, sig = _prep(x, sigmas)
     for i in _trange(len(sig) - 1, disable):
-        x, sigma_hat = _churn(x, sig, i, s_churn, s_tmin, s_tmax, s_noise, lib)
+        x, sigma_hat = _churn(x, sig, i, s_churn, s_tmin, s_tmax, s_noise, lib, noise_fn)
         denoised = model(x, _sigma_vec(x, sigma_hat), **extra_args).contiguous()
         if callback is not None:
             callback({'x': x, 'i': i, 'sigma': sigmas[i], 'sigma_hat': sigma_hat, 'denoised': denoised})
@@ -86,13 +87,13 @@ def sample_euler(model, x, sigmas, extra_args=None, callback=None, disable=None,
 
 
 def heun_step(model, x, sig, i, extra_args=None, callback=None, sigmas=None, s_churn=0., s_tmin=0.,
-              s_tmax=float('inf'), s_noise=1.):
+              s_tmax=float('inf'), s_noise=1., noise_fn=None):
     """One iteration i of sample_heun's loop on the host-side fp32 schedule `sig` (2 model calls,
     1 for the last step).  Exposed so a harness can time individual sampler steps."""
     extra_args = {} if extra_args is None else extra_args
     lib = L.load()
     n = x.numel()
-    x, sigma_hat = _churn(x, sig, i, s_churn, s_tmin, s_tmax, s_noise, lib)
+    x, sigma_hat = _churn(x, sig, i, s_churn, s_tmin, s_tmax, s_noise, lib, noise_fn)
     denoised = model(x, _sigma_vec(x, sigma_hat), **extra_args).contiguous()
     if callback is not None:
         callback({'x': x, 'i': i, 'sigma': (sigmas if sigmas is not None else sig)[i], 'sigma_hat': sigma_hat,
@@ -111,11 +112,11 @@ def heun_step(model, x, sig, i, extra_args=None, callback=None, sigmas=None, s_c
 
 
 def sample_heun(model, x, sigmas, extra_args=None, callback=None, disable=None, s_churn=0., s_tmin=0.,
-                s_tmax=float('inf'), s_noise=1.):
+                s_tmax=float('inf'), s_noise=1., noise_fn=None):
     """Algorithm 2 (Heun steps) from Karras et al. (2022); the last step (sigma -> 0) is Euler."""
     x, sig = _prep(x, sigmas)
     for i in _trange(len(sig) - 1, disable):
-        x = heun_step(model, x, sig, i, extra_args, callback, sigmas, s_churn, s_tmin, s_tmax, s_noise)
+        x = heun_step(model, x, sig, i, extra_args, callback, sigmas, s_churn, s_tmin, s_tmax, s_noise, noise_fn)
     return x
 
 

@@ -371,6 +371,35 @@ def test_sampler_golden(gold, tiny):
         assert dp < 1e-3, (sampler, dp)
 
 
+def test_sampler_churn_golden(gold, tiny):
+    """Stochastic samplers (s_churn > 0, k_diffusion/sampling.py:123-127,164-169) against the reference's churn
+    trajectories: the per-step noise is drawn on the CPU generator exactly as the reference capture drew it
+    (torch.manual_seed(7), one randn_like per step) and injected through `noise_fn`, so kdip_sampler_add_noise is
+    compared value-for-value (f32 mode)."""
+    import kdip_amd.condition as kc
+    import kdip_amd.sampling as ks
+    from kdip_amd.evaluation import psnr
+    models, D, sd, cfg = tiny
+    g = gold("sampler")
+    hop, oop, (y, yf), x0 = make_ops("gaussian_blur", gold)
+    meas = (y.cuda(), yf.cuda())
+    sig = ks.get_sigmas_karras(4, 0.01, 80, rho=7.0, device="cuda")
+    for sampler, fn in (("heun", ks.sample_heun), ("euler", ks.sample_euler)):
+        m = kc.ConditionOpenAIDenoiser(inner_model=models["f32"], diffusion=D, x0_cov_type="convert", recon_mse=None,
+                                       operator=hop, measurement=meas, guidance="I", device="cuda").eval()
+        torch.manual_seed(7)
+        cpu_noise = lambda x: torch.randn(x.shape)           # the reference's global CPU stream
+        x = fn(m, T(g["xT"]).cuda(), sig, disable=True, s_churn=80, s_tmin=0.05, s_tmax=50, s_noise=1.003, noise_fn=cpu_noise)
+        ref = T(g[f"{sampler}.x0_churn"])
+        err = float((x.cpu() - ref).abs().max())
+        dp = abs(float(psnr(x.cpu(), x0)) - float(psnr(ref, x0)))
+        print(f"\nchurn {sampler}: max-abs {err:.2e}, dPSNR {dp:.2e} dB")
+        assert err < 5e-3, (sampler, err)
+        assert dp < 1e-3, (sampler, dp)
+        # the churned trajectory must differ from the ode one (the noise really went in)
+        assert float((ref - T(g[f"{sampler}.x0"])).abs().max()) > 1e-3
+
+
 def test_sampler_dpmpp2m_golden(gold, tiny):
     """sample_dpmpp_2m on the HIP path (f32 mode) against the reference capture."""
     import kdip_amd.condition as kc
