@@ -59,9 +59,9 @@ int kdip_unet_finalize(kdip_unet* u);
  * Activations needed by kdip_unet_vjp are stashed inside the handle. */
 int kdip_unet_forward(kdip_unet* u, void* stream, const float* x_dev, const float* t_dev, int B, float in_scale,
                       float* out_dev, float* cov_out_dev, float* feature_dev);
-/* gx = (d out / d (x*in_scale))^T cot for the last kdip_unet_forward.  cot_dev [B,out_ch,S,S],
- * gx_dev [B,in_ch,S,S].  May be called repeatedly. */
-int kdip_unet_vjp(kdip_unet* u, void* stream, const float* cot_dev, float* gx_dev);
+/* gx = (d out / d (x*in_scale))^T cot for the last kdip_unet_forward.  cot_dev [B,out_ch,S,S] fp32,
+ * gx_dev [B,in_ch,S,S] fp32; B must equal the batch of that forward (KDIP_ERR_ARG otherwise).  May be called repeatedly. */
+int kdip_unet_vjp(kdip_unet* u, void* stream, const float* cot_dev, int B, float* gx_dev);
 /* bytes of device workspace currently held for batch B (allocated lazily, grows monotonically). */
 long kdip_unet_workspace_bytes(kdip_unet* u, int B);
 

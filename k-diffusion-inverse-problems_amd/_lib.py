@@ -20,7 +20,7 @@ SIGNATURES = {
     "kdip_unet_load": (C.c_int, [VP, C.c_char_p, VP, c_long_p, C.c_int]),
     "kdip_unet_finalize": (C.c_int, [VP]),
     "kdip_unet_forward": (C.c_int, [VP, VP, VP, VP, C.c_int, C.c_float, VP, VP, VP]),
-    "kdip_unet_vjp": (C.c_int, [VP, VP, VP, VP]),
+    "kdip_unet_vjp": (C.c_int, [VP, VP, VP, C.c_int, VP]),
     "kdip_unet_workspace_bytes": (C.c_long, [VP, C.c_int]),
     "kdip_op_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(VP)]),
     "kdip_op_destroy": (None, [VP]),

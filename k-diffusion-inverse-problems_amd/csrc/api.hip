@@ -1,5 +1,6 @@
 // C ABI of libkdip_hip (see include/kdip.h for the contract and reference citations).
 #include <vector>
+#include <mutex>
 #include "../../include/kdip.h"
 #include "kernels.h"
 #include "fftops.h"
@@ -55,8 +56,9 @@ int kdip_unet_forward(kdip_unet* u, void* stream, const float* x_dev, const floa
   KDIP_HIP_CHECK(hipSetDevice(u->u.device));
   return u->u.run(ST(stream), x_dev, t_dev, B, in_scale, out_dev, cov_out_dev, feature_dev, 1);
 }
-int kdip_unet_vjp(kdip_unet* u, void* stream, const float* cot_dev, float* gx_dev) {
+int kdip_unet_vjp(kdip_unet* u, void* stream, const float* cot_dev, int B, float* gx_dev) {
   KDIP_REQUIRE(u && cot_dev && gx_dev, "null argument");
+  KDIP_REQUIRE(B == u->u.last_B, "unet_vjp: cotangent batch %d does not match the batch %d of the last forward", B, u->u.last_B);
   KDIP_HIP_CHECK(hipSetDevice(u->u.device));
   return u->u.vjp(ST(stream), cot_dev, gx_dev);
 }
@@ -127,16 +129,22 @@ int kdip_blur_dense(void* stream, const float* x, const float* psf, int ks, int 
   return blur_dense_circ(ST(stream), x, psf, ks, S, planes, adjoint, out);
 }
 int kdip_fft2(void* stream, int S, const float* in, int real_in, float* out, int real_out, long planes, int inverse, float* tmp) {
-  static float2* tw = nullptr;   // per-process twiddles on the current device
-  static int tw_dev = -1;
+  // twiddle table per device, created once under a lock (this entry point may be called from several host threads / devices)
+  static std::mutex mu;
+  static float2* tw_by_dev[64] = {nullptr};
   int dev = 0;
   KDIP_HIP_CHECK(hipGetDevice(&dev));
-  if (!tw || tw_dev != dev) {
-    float2 host[128];
-    make_twiddles256(host);
-    KDIP_HIP_CHECK(hipMalloc((void**)&tw, sizeof(host)));
-    KDIP_HIP_CHECK(hipMemcpy(tw, host, sizeof(host), hipMemcpyHostToDevice));
-    tw_dev = dev;
+  KDIP_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
+  float2* tw;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (!tw_by_dev[dev]) {
+      float2 host[128];
+      make_twiddles256(host);
+      KDIP_HIP_CHECK(hipMalloc((void**)&tw_by_dev[dev], sizeof(host)));
+      KDIP_HIP_CHECK(hipMemcpy(tw_by_dev[dev], host, sizeof(host), hipMemcpyHostToDevice));
+    }
+    tw = tw_by_dev[dev];
   }
   return fft2(ST(stream), tw, S, in, real_in, (float2*)tmp, out, real_out, planes, inverse);
 }

@@ -1,5 +1,6 @@
 #include "common.h"
 #include <stdarg.h>
+#include <mutex>
 #include <vector>
 namespace kdip {
 thread_local std::string g_last_error;
@@ -15,8 +16,9 @@ int set_error(int code, const char* fmt, ...) {
 
 bool g_prof_on = false;
 struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; const char* tag; long d[4]; };
-static std::vector<ProfRec> g_recs;
-static ProfRec g_cur;
+static std::vector<ProfRec> g_recs;            // guarded by g_prof_mu (launches may come from several host threads)
+static std::mutex g_prof_mu;
+static thread_local ProfRec g_cur;             // the launch being bracketed on this host thread
 void prof_begin(hipStream_t st, int cls, double flops, double bytes, const char* tag, long d0, long d1, long d2, long d3) {
   if (!g_prof_on) return;
   g_cur.cls = cls; g_cur.flops = flops; g_cur.bytes = bytes; g_cur.tag = tag; g_cur.d[0] = d0; g_cur.d[1] = d1; g_cur.d[2] = d2; g_cur.d[3] = d3;
@@ -26,6 +28,7 @@ void prof_begin(hipStream_t st, int cls, double flops, double bytes, const char*
 void prof_end(hipStream_t st) {
   if (!g_prof_on) return;
   (void)hipEventRecord(g_cur.b, st);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   g_recs.push_back(g_cur);
 }
 static const char* kClassNames[PC_COUNT] = {"conv3x3_igemm_128x128", "conv3x3_igemm_128x64", "conv3x3_igemm_128x32",
@@ -36,6 +39,7 @@ static const char* kClassNames[PC_COUNT] = {"conv3x3_igemm_128x128", "conv3x3_ig
 extern "C" {
 int kdip_profile_enable(int on) {
   using namespace kdip;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   for (auto& r : g_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   g_recs.clear();
   g_prof_on = on != 0;

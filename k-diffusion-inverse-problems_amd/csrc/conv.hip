@@ -20,6 +20,8 @@
 // 64-wide wavefronts; 4 waves/block; XCD-aware block remap keeps all N-tiles of an
 // M-tile on one XCD's L2.  Build-time knobs (KDIP_*) exist for the A/B and ablation tools in tools/;
 // KDIP_TIMING=1 adds per-block phase stamps (tools/conv_phases.py).
+#include <atomic>
+#include <mutex>
 #include "common.h"
 #include "kernels.h"
 
@@ -846,10 +848,15 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
                px * (p.cin_real + p.Cout) * sizeof(T) + (double)NTAPS * p.cin_real * p.Cout * sizeof(T), "conv", p.B, p.H, p.cin_real, p.Cout);
   }
   if (lds > 48 * 1024) {
-    static size_t granted = 0;          // per instantiation: raise the dynamic-LDS cap once
-    if (lds > granted) {
+    // raise the dynamic-LDS cap once per (instantiation, device); the attribute is per device, and launches may come from
+    // several host threads (run_on_streams): an atomic device bit mask, setting the attribute twice is harmless
+    static std::atomic<unsigned long long> granted{0};
+    int dev = 0;
+    KDIP_HIP_CHECK(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(granted.load(std::memory_order_acquire) & bit)) {
       KDIP_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024)));
-      granted = 96 * 1024;
+      granted.fetch_or(bit, std::memory_order_release);
     }
   }
   // persistent launch (3x3 bf16, every tile on the fast epilogue): (resident blocks per CU) x (CUs) workgroups, a multiple
@@ -859,6 +866,8 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
     const size_t plds = (size_t)2 * npix * PIXB + (size_t)WAVES_M * WAVES_N * 16 * (NT * 32 * 4 + 16) + (size_t)BN / 4 * 2 * sizeof(float) +
                         (size_t)((NTAPS == 1 ? BM : 256) * (KC * SUBS * (int)sizeof(T) / 16) + WAVES_M * WAVES_N * 64 - 1) / (WAVES_M * WAVES_N * 64) *
                             (WAVES_M * WAVES_N * 64) * sizeof(int);                                   // + MAXV x NTHREADS parked offsets
+    static std::mutex pmu;              // (experimental -DKDIP_PERSIST=1 builds only) occupancy cache shared by host threads
+    std::lock_guard<std::mutex> plk(pmu);
     static int num_cu = 0, occ = 0;
     static size_t occ_lds = (size_t)-1;
     if (!num_cu) {

@@ -1,5 +1,6 @@
 // ADM UNet executor: plan + packed weights + forward (with activation stash) + input-VJP.
 #pragma once
+#include <array>
 #include <map>
 #include <string>
 #include <vector>
@@ -73,7 +74,8 @@ struct UNet {
   size_t zeros_fwd_end = 0;
   float* sk_ws = nullptr; long sk_ws_floats = 0;   // split-K workspace of the small-spatial convs (zeros arena; kept zero by the finalize kernel)
   std::map<std::pair<const void*, int>, double*> fused_stats;   // (tensor, channels) -> GroupNorm sums already accumulated by its producer
-  int ws_B = 0;
+  int ws_B = 0;                       // largest batch planned so far
+  std::map<int, std::array<size_t, 3>> planned;   // batch -> (persist, scratch, zeros) peak bytes of a dry forward + VJP at that batch
   bool dry = false;
   // state of the last forward (for the VJP)
   int last_B = 0; bool have_stash = false;

@@ -750,33 +750,41 @@ int UNet::vjp_impl(hipStream_t st, const float* cot_nchw, float* gx_nchw) {
 
 // ------------------------------------------------------------------------ workspace ----
 int UNet::ensure_workspace(int B) {
-  if (B <= ws_B) return KDIP_OK;
+  // Arena sizes come from a host-only dry run of forward + VJP AT THIS BATCH (tile choices, split-K eligibility and fused
+  // statistics depend on B, so peak usage is not monotone in B): every batch is planned once, before any kernel of a call
+  // at that batch is enqueued, and the arenas are regrown when a plan does not fit.  Arena::alloc therefore cannot run past
+  // `cap` in a real pass; the post-pass checks in run() / vjp() stay as internal assertions.
+  auto it = planned.find(B);
+  if (it == planned.end()) {
+    Arena sp = persist, ss = scratch, sz = zeros;
+    persist = Arena(); scratch = Arena(); zeros = Arena();
+    dry = true;
+    float dummy = 0;
+    int rc = forward_impl(nullptr, &dummy, &dummy, B, 1.f, &dummy, has_cov ? &dummy : nullptr, &dummy);
+    if (!rc) { last_B = B; rc = vjp_impl(nullptr, &dummy, &dummy); }
+    dry = false;
+    have_stash = false;
+    std::array<size_t, 3> pk = {persist.peak + (1 << 20), scratch.peak + (1 << 20), zeros.peak + 4096};
+    persist = sp; scratch = ss; zeros = sz;
+    if (rc) return rc;
+    it = planned.emplace(B, pk).first;
+  }
+  const std::array<size_t, 3>& pk = it->second;
+  if (pk[0] <= persist.cap && pk[1] <= scratch.cap && pk[2] <= zeros.cap) return KDIP_OK;
   KDIP_HIP_CHECK(hipSetDevice(device));
-  // dry run of forward + vjp to measure both arenas
-  if (persist.base) { KDIP_HIP_CHECK(hipFree(persist.base)); persist.base = nullptr; }
-  if (scratch.base) { KDIP_HIP_CHECK(hipFree(scratch.base)); scratch.base = nullptr; }
-  if (zeros.base) { KDIP_HIP_CHECK(hipFree(zeros.base)); zeros.base = nullptr; }
-  persist = Arena(); scratch = Arena(); zeros = Arena();
-  dry = true;
-  float dummy = 0;
-  int rc = forward_impl(nullptr, &dummy, &dummy, B, 1.f, &dummy, has_cov ? &dummy : nullptr, &dummy);
-  size_t fwd_off = persist.off;
-  if (!rc) { last_B = B; rc = vjp_impl(nullptr, &dummy, &dummy); }
-  dry = false;
-  have_stash = false;
-  if (rc) return rc;
-  (void)fwd_off;
-  size_t pp = persist.peak + (1 << 20), sp = scratch.peak + (1 << 20), zp = zeros.peak + 4096;
-  persist = Arena(); scratch = Arena(); zeros = Arena();
-  if (hipMalloc((void**)&zeros.base, zp) != hipSuccess)
-    return set_error(KDIP_ERR_NOMEM, "workspace: hipMalloc(%zu) failed", zp);
-  zeros.cap = zp;
-  if (hipMalloc((void**)&persist.base, pp) != hipSuccess)
-    return set_error(KDIP_ERR_NOMEM, "workspace: hipMalloc(%zu) failed", pp);
-  if (hipMalloc((void**)&scratch.base, sp) != hipSuccess)
-    return set_error(KDIP_ERR_NOMEM, "workspace: hipMalloc(%zu) failed", sp);
-  persist.cap = pp; scratch.cap = sp;
-  ws_B = B;
+  KDIP_HIP_CHECK(hipDeviceSynchronize());           // kernels of earlier calls may still use the old arenas
+  auto grow = [&](Arena& a, size_t need, const char* what) -> int {
+    if (need <= a.cap) return KDIP_OK;
+    if (a.base) { KDIP_HIP_CHECK(hipFree(a.base)); }
+    a = Arena();
+    if (hipMalloc((void**)&a.base, need) != hipSuccess) return set_error(KDIP_ERR_NOMEM, "workspace (%s): hipMalloc(%zu) failed", what, need);
+    a.cap = need;
+    return KDIP_OK;
+  };
+  CK(grow(zeros, pk[2], "zeros"));
+  CK(grow(persist, pk[0], "persist"));
+  CK(grow(scratch, pk[1], "scratch"));
+  if (B > ws_B) ws_B = B;
   return KDIP_OK;
 }
 

@@ -349,7 +349,9 @@ class InpaintingOperator(LinearOperator):
         return self._apply(r, False, r.shape)
 
     def generate_mask(self, mask_opt):
-        return MaskGenerator(**mask_opt)(torch.empty(*self.in_shape))
+        # the reference draws torch.randn(*in_shape) here (measurements.py:242): only its shape is used, but the draw advances
+        # the torch CPU generator, so it is kept to leave the random stream of everything that follows unchanged
+        return MaskGenerator(**mask_opt)(torch.randn(*self.in_shape))
 
 
 class MaskGenerator:

@@ -60,7 +60,7 @@ class OrthoTransform:
         assert x.is_cuda and x.dtype == torch.float32 and x.ndim == 4 and x.shape[1] == 3 and x.shape[2] == x.shape[3]
         x = x.contiguous()
         out = torch.empty_like(x)
-        h = _ctx(x.shape[-1], self.code, x.device.index or 0)
+        h = _ctx(x.shape[-1], self.code, x.device.index if x.device.index is not None else torch.cuda.current_device())
         L.check(L.load().kdip_op_ortho(h, L.stream(), L.ptr(x), x.shape[0], int(inverse), L.ptr(out)))
         return out
 

@@ -75,7 +75,7 @@ class UNetModel:
         h = C.c_void_p()
         ads = (C.c_int * len(self.attention_ds))(*self.attention_ds)
         cms = (C.c_int * len(self.channel_mult))(*self.channel_mult)
-        L.check(self.lib.kdip_unet_create(dev.index or 0, L.BF16 if dtype == "bf16" else L.F32, image_size, in_channels,
+        L.check(self.lib.kdip_unet_create(dev.index if dev.index is not None else torch.cuda.current_device(), L.BF16 if dtype == "bf16" else L.F32, image_size, in_channels,
                                           model_channels, out_channels, num_res_blocks, ads, len(self.attention_ds),
                                           cms, len(self.channel_mult), num_head_channels, C.byref(h)))
         self._h = h
@@ -123,9 +123,14 @@ class UNetModel:
 
     def vjp(self, cot):
         """(d out / d x_in)^T cot for the last forward; cot [B,6,S,S] -> [B,3,S,S]."""
+        if not (cot.is_cuda and cot.dtype == torch.float32 and cot.device == self.device):
+            raise L.KdipError(f"vjp: cotangent must be a float32 tensor on {self.device} (got {cot.dtype} on {cot.device})")
+        if tuple(cot.shape[1:]) != (self.out_channels, self.image_size, self.image_size):
+            raise L.KdipError(f"vjp: cotangent shape {tuple(cot.shape)} does not match [B, {self.out_channels}, {self.image_size}, {self.image_size}]")
         cot = cot.contiguous()
-        gx = torch.empty(cot.shape[0], self.in_channels, self.image_size, self.image_size, device=cot.device)
-        L.check(self.lib.kdip_unet_vjp(self._h, L.stream(), L.ptr(cot), L.ptr(gx)))
+        B = cot.shape[0]
+        gx = torch.empty(B, self.in_channels, self.image_size, self.image_size, device=cot.device)
+        L.check(self.lib.kdip_unet_vjp(self._h, L.stream(), L.ptr(cot), B, L.ptr(gx)))   # the library rejects B != batch of the last forward
         return gx
 
     def forward(self, x, timesteps, y=None, return_feature=False):

@@ -154,10 +154,13 @@ def main():
 
     operator_config = load_yaml(args.operator_config)
     import numpy as np
+    np.random.seed(args.seed)                      # same mask on every rank and in every run (masks come from numpy's global stream)
     rng_state = np.random.get_state()
+    trng_state = torch.get_rng_state()
     operators = []
     for _ in range(nstreams):                      # identical operators (same mask draw), one device context per stream
         np.random.set_state(rng_state)
+        torch.set_rng_state(trng_state)
         operators.append(km.get_operator(device=device, **operator_config))
     operator = operators[0]
     if env.is_main_process:
@@ -175,11 +178,14 @@ def main():
             s = ks.get_sigmas_karras(1000, sigma_min, sigma_max, device="cpu")[:-1]
             recon_mse = {"sigmas": s, "mse_list": s ** 2 / (1 + s ** 2) * 0.5}
 
-    torch.manual_seed(args.seed + env.rank)
     metrics_list = []
     for i, x0 in enumerate(images):
         x0 = x0[None].to(device)
+        # the measurement (its noise) is a property of image i, identical on every rank: all ranks' samples are posterior
+        # samples of the SAME measurement, the one rank 0 saves and scores; x_T and churn noise are then seeded per rank
+        torch.manual_seed(args.seed * 1000003 + i)
         measurement = operator.forward(x0.clone(), flatten=True)
+        torch.manual_seed(args.seed + 7919 * (i + 1) + env.rank)
         def make_model(k):
             if v2:
                 from kdip_amd.external import OpenAIDenoiserV2
