@@ -160,6 +160,16 @@ int kdip_profile_dump(const char* path);
 int kdip_test_conv(void* stream, int dtype, int ntaps, const float* x_nchw_dev, int B, int Cin, int H, int W,
                    const float* w_host, const float* bias_host, int Cout, int transpose_flip, float* y_nchw_dev,
                    int storage_out /* 0: fp32 NHWC epilogue (output heads); 1: storage-dtype epilogue (UNet-internal) */);
+/* Second-generation bf16 3x3 conv (csrc/conv3.hip) with its fused GroupNorm staging transforms and epilogue statistics.
+ * Tensor arguments are device fp32 NCHW; tf 1: tf_coef [B][Cin][2] = (a, b); tf 2: x = dy, x2 = GroupNorm input,
+ * tf_coef [B][Cin][4] = (a, b, k0, k1); st_mode 1 / 2: sums_dev [B][32][2] (fp64) receives the GroupNorm forward / backward
+ * sums of the output (mode 2: stx = GroupNorm input of the output, st_coef [B][Cout][2], st_mr [B][32][2]).
+ * reps > 1: mean HIP-event microseconds per launch in *avg_us_host. */
+int kdip_test_conv3(void* stream, const float* x_nchw_dev, const float* x2_nchw_dev, int B, int Cin, int H, int W,
+                    const float* w_host, const float* bias_host, int Cout, int transpose_flip, int tf, const float* tf_coef_dev,
+                    const float* res_nchw_dev, int in_ups, int res_ups, int st_mode, const float* stx_nchw_dev,
+                    const float* st_coef_dev, const float* st_mr_dev, float* y_nchw_dev, double* sums_dev, int reps,
+                    float* avg_us_host);
 int kdip_test_groupnorm(void* stream, int dtype, const float* x_nchw_dev, int B, int C, int H, int W,
                         const float* gamma_host, const float* beta_host, const float* film_host, int silu,
                         float* y_nchw_dev, const float* dy_nchw_dev, float* dx_nchw_dev);

@@ -226,6 +226,57 @@ int kdip_test_conv(void* stream, int dtype, int ntaps, const float* x_nchw, int 
   return KDIP_OK;
 }
 
+// conv3.hip through the C ABI: every tensor argument is a device fp32 NCHW tensor (converted to the bf16 NHWC storage
+// layout here), coefficient tables are device fp32 arrays in the layouts of Conv3Fuse; reps > 1 re-runs the conv and
+// reports the mean HIP-event time per launch in *avg_us_host.
+int kdip_test_conv3(void* stream, const float* x_nchw, const float* x2_nchw, int B, int Cin, int H, int W, const float* w_host,
+                    const float* bias_host, int Cout, int transpose_flip, int tf, const float* tf_coef_dev, const float* res_nchw,
+                    int in_ups, int res_ups, int st_mode, const float* stx_nchw, const float* st_coef_dev, const float* st_mr_dev,
+                    float* y_nchw, double* sums_dev, int reps, float* avg_us_host) {
+  hipStream_t st = ST(stream);
+  const DType dt = DT_BF16;
+  const size_t es = 2;
+  const int Ci = transpose_flip ? Cout : Cin, Co = transpose_flip ? Cin : Cout;
+  const int cpad = pad32i(Ci);
+  KDIP_REQUIRE(Ci == cpad && Co % 128 == 0, "test_conv3: Cin must be a multiple of 32 and Cout of 128");
+  std::vector<char> buf(packed_weight_bytes(dt, 9, cpad, Co));
+  pack_conv_weight(dt, w_host, Cout, Cin, 9, transpose_flip, cpad, buf.data());
+  void *wp = nullptr, *xin = nullptr, *x2 = nullptr, *res = nullptr, *stx = nullptr, *ys = nullptr; float* bias = nullptr;
+  const int Hi = in_ups ? H / 2 : H, Wi = in_ups ? W / 2 : W, Hr = res_ups ? H / 2 : H, Wr = res_ups ? W / 2 : W;
+  KDIP_HIP_CHECK(hipMalloc(&wp, buf.size()));
+  KDIP_HIP_CHECK(hipMemcpy(wp, buf.data(), buf.size(), hipMemcpyHostToDevice));
+  if (bias_host) { KDIP_HIP_CHECK(hipMalloc((void**)&bias, sizeof(float) * Co)); KDIP_HIP_CHECK(hipMemcpy(bias, bias_host, sizeof(float) * Co, hipMemcpyHostToDevice)); }
+  KDIP_HIP_CHECK(hipMalloc(&xin, es * (size_t)B * Hi * Wi * cpad));
+  KDIP_HIP_CHECK(hipMalloc(&ys, es * (size_t)B * H * W * Co));
+  int rc = nchw_to_nhwc(st, dt, x_nchw, B, Ci, Hi, Wi, 1.f, xin, cpad, cpad);
+  if (x2_nchw) { KDIP_HIP_CHECK(hipMalloc(&x2, es * (size_t)B * H * W * cpad)); if (!rc) rc = nchw_to_nhwc(st, dt, x2_nchw, B, Ci, H, W, 1.f, x2, cpad, cpad); }
+  if (res_nchw) { KDIP_HIP_CHECK(hipMalloc(&res, es * (size_t)B * Hr * Wr * Co)); if (!rc) rc = nchw_to_nhwc(st, dt, res_nchw, B, Co, Hr, Wr, 1.f, res, Co, Co); }
+  if (stx_nchw) { KDIP_HIP_CHECK(hipMalloc(&stx, es * (size_t)B * H * W * Co)); if (!rc) rc = nchw_to_nhwc(st, dt, stx_nchw, B, Co, H, W, 1.f, stx, Co, Co); }
+  Conv3Fuse fu;
+  fu.in_ups = in_ups; fu.res_ups = res_ups; fu.tf = tf; fu.tf_silu = 1; fu.tf_coef = tf_coef_dev; fu.x2 = x2; fu.ldx2 = cpad;
+  fu.st_mode = st_mode; fu.st_silu = 1; fu.st_sums = sums_dev; fu.st_x = stx; fu.st_ldx = Co; fu.st_coef = st_coef_dev; fu.st_mr = st_mr_dev;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (reps > 1) { KDIP_HIP_CHECK(hipEventCreate(&e0)); KDIP_HIP_CHECK(hipEventCreate(&e1)); }
+  for (int r = 0; r < (reps > 1 ? reps + 1 : 1) && !rc; ++r) {
+    if (r == 1) KDIP_HIP_CHECK(hipEventRecord(e0, st));          // launch 0 is the warm-up
+    if (sums_dev) KDIP_HIP_CHECK(hipMemsetAsync(sums_dev, 0, sizeof(double) * B * 64, st));
+    rc = conv3_forward(st, xin, cpad, B, H, W, cpad, wp, bias, Co, ys, Co, res, Co, &fu, Ci);
+  }
+  if (reps > 1 && !rc) {
+    KDIP_HIP_CHECK(hipEventRecord(e1, st));
+    KDIP_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0; KDIP_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (avg_us_host) *avg_us_host = ms * 1e3f / reps;
+  }
+  if (!rc) rc = nhwc_T_to_nchw_f32(st, dt, ys, Co, B, Co, H, W, y_nchw);
+  hipError_t e = hipStreamSynchronize(st);
+  if (e0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
+  (void)hipFree(wp); (void)hipFree(xin); (void)hipFree(ys); if (x2) (void)hipFree(x2); if (res) (void)hipFree(res); if (stx) (void)hipFree(stx); if (bias) (void)hipFree(bias);
+  if (rc) return rc;
+  KDIP_HIP_CHECK(e);
+  return KDIP_OK;
+}
+
 int kdip_test_groupnorm(void* stream, int dtype, const float* x_nchw, int B, int C, int H, int W, const float* gamma_host,
                         const float* beta_host, const float* film_host, int silu, float* y_nchw, const float* dy_nchw,
                         float* dx_nchw) {

@@ -1,0 +1,424 @@
+// bf16 implicit-GEMM 3x3 convolution for the large feature maps of the UNet (W >= 32, Cout % 128 == 0) on CDNA4 MFMA,
+// second generation.  Replaces nn.Conv2d(3x3, pad 1) of guided_diffusion/unet.py:182-222 and its input-gradient, WITH the
+// GroupNorm + FiLM + SiLU that precedes every such conv in a ResBlock (unet.py:183-184,207-208,249-253) applied while the
+// input patch is staged (forward), and with the GroupNorm backward `dx = a*dz - (k0 + k1*x)` applied while the dgrad conv's
+// input patch is staged (VJP): the activated tensor / the GroupNorm input-gradient never exist in HBM.
+//
+// GEMM view per block: D[cout 128][pixel 256] += W[cout][k] * X[k][pixel], k = (tap, cin).
+//   * orientation: cout is the MFMA ROW index, pixels the COLUMN index, so after v_mfma_f32_32x32x16_bf16 a lane owns, for
+//     ONE pixel (lane & 31), channel quads 8q + 4(lane >> 5) + {0..3}: the epilogue packs them to bf16 in registers, pairs
+//     quads with v_permlane32_swap into 16-byte vectors and stores straight to NHWC -- no LDS transpose, no barrier.
+//   * block = 4 waves, tile = 8 x 32 pixels x 128 cout, wave tile = 4 pixel rows (4 MFMA column tiles) x 64 cout;
+//     2 blocks per CU (<= 256 VGPRs, 70 KB LDS each).
+//   * X (activations): a 10 x 34 halo patch x 32 channels per chunk, double-buffered in LDS with an 80-byte pixel pitch: an
+//     MFMA column tile is one 32-pixel patch row, so every 16-lane group of ds_read_b128 hits 16 distinct 16-byte slots
+//     (conflict free; the first-generation kernel's 16-wide patches collided on 2 of 16 slots).  Staging goes through
+//     registers because the GroupNorm transform is applied on the way (packed back to bf16, halo / padding pixels stay zero).
+//   * W (weights): the host-packed fragment order of conv.hip ([tap][k-step][n-tile][lane][16 B]) is streamed stage by stage
+//     (one tap of one 32-channel chunk = 8 KiB) into a 2-slot LDS ring with global_load_lds_dwordx4 (no VGPR round trip);
+//     the two waves that share a cout half read each fragment from LDS instead of each pulling it through the CU's L1
+//     (the first-generation kernel needed the full 64 B/clk of the vector cache for the B fragments alone).
+//   * one barrier per stage (16 MFMAs per wave); the weight DMA of stage s+1 and the patch loads of chunk c+1 are in flight
+//     under the MFMAs of stage s.
+//   * epilogue: bias, residual (optionally read through a fused nearest x2 upsample), bf16 store, and the GroupNorm
+//     forward sums (mode 1) or backward sums (mode 2) of the OUTPUT accumulated per lane and combined once per block.
+#include <atomic>
+#include "common.h"
+#include "kernels.h"
+
+namespace kdip {
+
+namespace {
+
+constexpr int C3_TH = 8, C3_TW = 32, C3_BM = C3_TH * C3_TW, C3_BN = 128;
+constexpr int C3_PW = C3_TW + 2, C3_PH = C3_TH + 2, C3_NPIX = C3_PW * C3_PH;   // 34 x 10 = 340 halo pixels
+constexpr int C3_PIXB = 80;                               // LDS pixel pitch: 64 B of channels + 16 B pad
+constexpr int C3_ABUF = C3_NPIX * C3_PIXB;                // 27200 B per patch buffer
+constexpr int C3_BSLOT = 8192;                            // one weight stage: 2 k-steps x 4 n-tiles x 1 KiB
+constexpr int C3_MAXV = (C3_NPIX * 4 + 255) / 256;        // staged 16-byte vectors per thread (6)
+constexpr int C3_MAXCIN = 512;                            // transform coefficient table: <= 512 input channels x 16 B
+constexpr int C3_TAB = 2 * C3_ABUF + 2 * C3_BSLOT;        // LDS offset of the table
+constexpr int c3_lds_bytes(int tf) { return C3_TAB + (tf == 0 ? 0 : (tf == 1 ? C3_MAXCIN * 8 : C3_MAXCIN * 16)); }   // 70784 / 74880 / 78976 B
+
+struct Conv3Params {
+  const bf16_t* x; long ldx;          // staged tensor (TF 0/1: the conv input or GroupNorm input; TF 2: dy of the GroupNorm output)
+  const bf16_t* x2; long ldx2;        // TF 2: the GroupNorm input
+  const uint4* wp;                    // packed weights (pack_conv_weight, bf16)
+  const float* bias;                  // [Cout] or null
+  const bf16_t* res; long ldr;        // residual or null
+  bf16_t* y; long ldy;
+  int B, H, W, Cin, Cout;
+  int ntilesN, tilesX, tilesY, mtiles, nblkN;
+  int in_ups, res_ups;
+  const float* tf_coef;               // TF 1: [B][Cin][2] (a, b); TF 2: [B][Cin][4] (a, b, k0, k1)
+  int tf_silu;
+  int st_silu;
+  double* st_sums;                    // [B][32][2]
+  const bf16_t* st_x; long st_ldx;    // mode 2: GroupNorm input of the produced gradient
+  const float* st_coef;               // mode 2: [B][Cout][2]
+  const float* st_mr;                 // mode 2: [B][32][2]
+};
+
+__device__ __forceinline__ f32x16 mfma_bf16(const uint4& a, const uint4& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// TF: staging transform (0 none, 1 GroupNorm forward apply, 2 GroupNorm backward apply); STM: statistics mode of the output
+template <int TF, int STM>
+__global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  // ---- XCD-aware bijective block -> tile map (all n-blocks of an m-tile and neighbouring tiles share one XCD's L2)
+  const int ntiles = p.mtiles * p.nblkN;
+  const int xq = ntiles >> 3, xr = ntiles & 7, xcd = blockIdx.x & 7, xj = blockIdx.x >> 3;
+  const int bid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xj;
+  if (xj >= xq + (xcd < xr ? 1 : 0)) return;
+  const int mtile = bid / p.nblkN, nb = bid - mtile * p.nblkN;
+  const int tpi = p.tilesX * p.tilesY;
+  const int img = mtile / tpi, trem = mtile - img * tpi;
+  const int ty0 = trem / p.tilesX;
+  const int y0 = ty0 * C3_TH, x0 = (trem - ty0 * p.tilesX) * C3_TW;
+
+  // ---- staging descriptors: vector v = tid + 256 i -> (halo pixel v >> 2, 16-byte channel group v & 3 = tid & 3)
+  int goff[C3_MAXV];                   // source offset in 16-byte units, -1 = zero fill
+  int goff2[TF == 2 ? C3_MAXV : 1];
+#pragma unroll
+  for (int i = 0; i < C3_MAXV; ++i) {
+    const int v = tid + i * 256, pix = v >> 2;
+    const int hy = pix / C3_PW, hx = pix - hy * C3_PW;
+    const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+    goff[i] = -1;
+    if (TF == 2) goff2[i] = -1;
+    if (pix < C3_NPIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+      const long spix = p.in_ups ? ((long)img * (p.H >> 1) + (gy >> 1)) * (p.W >> 1) + (gx >> 1) : ((long)img * p.H + gy) * p.W + gx;
+      goff[i] = (int)(spix * (p.ldx >> 3)) + (tid & 3);
+      if (TF == 2) goff2[i] = (int)(spix * (p.ldx2 >> 3)) + (tid & 3);
+    }
+  }
+  const int nchunks = p.Cin >> 5;
+  // The patch of chunk c+1 is staged one 16-byte vector per thread per tap: vector i is requested at tap i of chunk c and
+  // transformed + written to the other patch buffer at tap i+1 (every stage ends with a barrier that also drains the
+  // loads, so the data is there); at most one vector (two for TF 2) is live, and the transform's VALU work is spread evenly
+  // under the MFMAs of six stages.  The per-channel coefficients live in an LDS table filled once per block.
+  uint4 sreg = make_uint4(0, 0, 0, 0), sreg2 = make_uint4(0, 0, 0, 0);
+  auto vec_load = [&](int c, int i) {
+    sreg = make_uint4(0, 0, 0, 0);
+    if (goff[i] >= 0) sreg = *(const uint4*)(p.x + (long)goff[i] * 8 + c * 32);
+    if (TF == 2) {
+      sreg2 = make_uint4(0, 0, 0, 0);
+      if (goff2[i] >= 0) sreg2 = *(const uint4*)(p.x2 + (long)goff2[i] * 8 + c * 32);
+    }
+  };
+  auto vec_write = [&](int c, int i) {
+    const int v = tid + i * 256, pix = v >> 2;
+    if (pix >= C3_NPIX) return;
+    uint4 o = sreg;
+    if (TF == 1) {
+      const float4* tab = (const float4*)(smem + C3_TAB) + (c * 32 + (tid & 3) * 8) / 2;    // (a, b) pairs: 2 channels per float4
+      float f[8];
+      unpack16<bf16_t>(o, f);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 k = tab[j];
+        const float z0 = k.x * f[2 * j] + k.y, z1 = k.z * f[2 * j + 1] + k.w;
+        f[2 * j] = silu_fast(z0);
+        f[2 * j + 1] = silu_fast(z1);
+      }
+      o = pack16<bf16_t>(f);
+      if (goff[i] < 0) o = make_uint4(0, 0, 0, 0);          // conv zero padding applies to the ACTIVATED tensor
+    } else if (TF == 2) {
+      const float4* tab = (const float4*)(smem + C3_TAB) + (c * 32 + (tid & 3) * 8);        // (a, b, k0, k1) per channel
+      float fd[8], fx[8];
+      unpack16<bf16_t>(o, fd);
+      unpack16<bf16_t>(sreg2, fx);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float4 k = tab[e];
+        const float z = k.x * fx[e] + k.y;
+        const float dz = fd[e] * silu_grad_fast(z);
+        fd[e] = k.x * dz - (k.z + k.w * fx[e]);
+      }
+      o = pack16<bf16_t>(fd);
+      if (goff[i] < 0) o = make_uint4(0, 0, 0, 0);
+    }
+    *(uint4*)(smem + (c & 1) * C3_ABUF + pix * C3_PIXB + (tid & 3) * 16) = o;
+  };
+  if (TF == 1) {
+    const float2* src = (const float2*)(p.tf_coef + (long)img * p.Cin * 2);
+    for (int ch = tid; ch < p.Cin; ch += 256) ((float2*)(smem + C3_TAB))[ch] = src[ch];
+  } else if (TF == 2) {
+    const float4* src = (const float4*)(p.tf_coef + (long)img * p.Cin * 4);
+    for (int ch = tid; ch < p.Cin; ch += 256) ((float4*)(smem + C3_TAB))[ch] = src[ch];
+  }
+
+  // ---- weight stream: stage (chunk c, tap t) = k-steps 2c, 2c+1 of tap t, n-tiles 4 nb .. 4 nb + 3
+  const long kStride = (long)p.ntilesN * 64, tapStride = (long)(p.Cin >> 4) * kStride;
+  const uint4* wthr = p.wp + (long)nb * 256 + tid;       // this thread's 16 bytes inside a k-step row
+  auto dma_b = [&](int c, int tap, int slot) {
+    const uint4* g = wthr + tap * tapStride + (long)(2 * c) * kStride;
+    unsigned char* l = smem + 2 * C3_ABUF + slot * C3_BSLOT + wave * 1024;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + kStride), (__attribute__((address_space(3))) void*)(l + 4096), 16, 0, 0);
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  // ---- prologue: weight stage 0 in flight, then the whole first patch (coefficient table first: one barrier)
+  dma_b(0, 0, 0);
+  if (TF) __syncthreads();
+#pragma unroll
+  for (int i = 0; i < C3_MAXV; ++i) {
+    vec_load(0, i);
+    vec_write(0, i);
+  }
+  __syncthreads();
+
+  const int a_lane = (wm * 4 * C3_PW + (lane & 31)) * C3_PIXB + (lane >> 5) * 16;   // + (mt + ty) * PW * PIXB + tx * PIXB + ks * 32
+  const int b_lane = 2 * C3_ABUF + (wn * 2 * 64 + lane) * 16;                       // + slot * BSLOT + (ks * 4 + nt) * 1024
+
+  for (int c = 0; c < nchunks; ++c) {
+    const unsigned char* ab = smem + (c & 1) * C3_ABUF + a_lane;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int slot = (c + tap) & 1;               // stage index c * 9 + tap, parity = (c + tap) & 1
+      {
+        const int tn = tap == 8 ? 0 : tap + 1, cn = tap == 8 ? c + 1 : c;
+        if (cn < nchunks) dma_b(cn, tn, slot ^ 1);
+      }
+      if (tap >= 1 && tap <= C3_MAXV && c + 1 < nchunks) vec_write(c + 1, tap - 1);
+      if (tap < C3_MAXV && c + 1 < nchunks) vec_load(c + 1, tap);
+      const unsigned char* bb = smem + b_lane + slot * C3_BSLOT;
+      const int toff = ((tap / 3) * C3_PW + (tap % 3)) * C3_PIXB;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        uint4 bf[2], af[4];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) bf[nt] = *(const uint4*)(bb + (ks * 4 + nt) * 1024);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) af[mt] = *(const uint4*)(ab + mt * C3_PW * C3_PIXB + toff + ks * 32);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma_bf16(bf[nt], af[mt], acc[mt][nt]);
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue (no LDS traffic until the statistics combine).  Addresses = wave-uniform 64-bit row bases + one 32-bit
+  // per-lane byte offset per tensor (the loads / stores use the saddr + voffset form: no 64-bit vector arithmetic).
+  const int h = lane >> 5, pl = lane & 31;
+  const int cpg = p.Cout >> 5;
+  const int nbase = nb * C3_BN + wn * 64;                 // first channel of this wave
+  const int row0 = y0 + wm * 4;                           // first pixel row of this wave
+  float s1[8], s2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
+  char* const yb = (char*)(p.y + ((long)img * p.H + row0) * p.W * p.ldy + nbase);
+  const unsigned rsy = (unsigned)(p.W * p.ldy * 2), lane_y = (unsigned)(((x0 + pl) * p.ldy + 8 * h) * 2);
+  const int Hr = p.res_ups ? p.H >> 1 : p.H, Wr = p.res_ups ? p.W >> 1 : p.W;
+  const char* const rb = (const char*)(p.res + (long)img * Hr * Wr * p.ldr + nbase);
+  const unsigned rsr = (unsigned)(Wr * p.ldr * 2), lane_r = (unsigned)((((p.res_ups ? (x0 + pl) >> 1 : x0 + pl)) * p.ldr + 4 * h) * 2);
+  const char* const xb = (const char*)(p.st_x + ((long)img * p.H + row0) * p.W * p.st_ldx + nbase);
+  const unsigned rsx = (unsigned)(p.W * p.st_ldx * 2), lane_x = (unsigned)(((x0 + pl) * p.st_ldx + 4 * h) * 2);
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int cq = nbase + nt * 32 + 16 * k + 4 * h;    // quad 2k: channels cq .. cq+3; quad 2k+1: cq+8 .. cq+11
+      const unsigned coff = (unsigned)((nt * 32 + 16 * k) * 2);
+      float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+      if (p.bias) { b0 = *(const float4*)(p.bias + cq); b1 = *(const float4*)(p.bias + cq + 8); }
+      float4 ka[4];                                       // mode 2: (a, b) of the 8 channels
+      float gm[2], gr[2];
+      if (STM == 2) {
+        const float4* cc = (const float4*)(p.st_coef + ((long)img * p.Cout + cq) * 2);
+        ka[0] = cc[0]; ka[1] = cc[1]; ka[2] = cc[4]; ka[3] = cc[5];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const float2 m = *(const float2*)(p.st_mr + ((long)img * 32 + (cq + 8 * q) / cpg) * 2);
+          gm[q] = m.x; gr[q] = m.y;
+        }
+      }
+      uint2 rr[4][2], xx[4][2];
+      if (p.res) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const char* r = rb + (unsigned)(p.res_ups ? (row0 + mt) >> 1 : row0 + mt) * rsr + coff;
+          rr[mt][0] = *(const uint2*)(r + lane_r);
+          rr[mt][1] = *(const uint2*)(r + lane_r + 16);
+        }
+      }
+      if (STM == 2) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const char* r = xb + mt * rsx + coff;
+          xx[mt][0] = *(const uint2*)(r + lane_x);
+          xx[mt][1] = *(const uint2*)(r + lane_x + 16);
+        }
+      }
+      float t1[2] = {0.f, 0.f}, t2[2] = {0.f, 0.f};
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        float v[8];
+        v[0] = acc[mt][nt][8 * k + 0] + b0.x; v[1] = acc[mt][nt][8 * k + 1] + b0.y;
+        v[2] = acc[mt][nt][8 * k + 2] + b0.z; v[3] = acc[mt][nt][8 * k + 3] + b0.w;
+        v[4] = acc[mt][nt][8 * k + 4] + b1.x; v[5] = acc[mt][nt][8 * k + 5] + b1.y;
+        v[6] = acc[mt][nt][8 * k + 6] + b1.z; v[7] = acc[mt][nt][8 * k + 7] + b1.w;
+        if (p.res) {
+          v[0] += bf_lo(rr[mt][0].x); v[1] += bf_hi(rr[mt][0].x); v[2] += bf_lo(rr[mt][0].y); v[3] += bf_hi(rr[mt][0].y);
+          v[4] += bf_lo(rr[mt][1].x); v[5] += bf_hi(rr[mt][1].x); v[6] += bf_lo(rr[mt][1].y); v[7] += bf_hi(rr[mt][1].y);
+        }
+        uint32_t w0x = pack_bf16x2(v[0], v[1]), w0y = pack_bf16x2(v[2], v[3]);
+        uint32_t w1x = pack_bf16x2(v[4], v[5]), w1y = pack_bf16x2(v[6], v[7]);
+        if (STM == 1) {     // statistics of the stored (rounded) values
+          const float r0 = bf_lo(w0x), r1 = bf_hi(w0x), r2 = bf_lo(w0y), r3 = bf_hi(w0y);
+          const float r4 = bf_lo(w1x), r5 = bf_hi(w1x), r6 = bf_lo(w1y), r7 = bf_hi(w1y);
+          t1[0] += (r0 + r1) + (r2 + r3); t2[0] += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
+          t1[1] += (r4 + r5) + (r6 + r7); t2[1] += (r4 * r4 + r5 * r5) + (r6 * r6 + r7 * r7);
+        } else if (STM == 2) {
+          const float dy[8] = {bf_lo(w0x), bf_hi(w0x), bf_lo(w0y), bf_hi(w0y), bf_lo(w1x), bf_hi(w1x), bf_lo(w1y), bf_hi(w1y)};
+          const float xg[8] = {bf_lo(xx[mt][0].x), bf_hi(xx[mt][0].x), bf_lo(xx[mt][0].y), bf_hi(xx[mt][0].y),
+                               bf_lo(xx[mt][1].x), bf_hi(xx[mt][1].x), bf_lo(xx[mt][1].y), bf_hi(xx[mt][1].y)};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float4 kk = ka[e >> 1];
+            const float a = (e & 1) ? kk.z : kk.x, b = (e & 1) ? kk.w : kk.y;
+            const float z = a * xg[e] + b;
+            const float dz = dy[e] * silu_grad_fast(z);
+            const float adz = a * dz;
+            t1[e >> 2] += adz;
+            t2[e >> 2] += adz * xg[e];
+          }
+        }
+        // lanes l and l + 32 hold the same pixel: after the swaps lanes < 32 own channels 16k .. 16k+7 and lanes >= 32
+        // own 16k+8 .. 16k+15 of their n-tile -> one 16-byte store each
+        {
+          auto r = __builtin_amdgcn_permlane32_swap(w0x, w1x, false, false);
+          w0x = r[0]; w1x = r[1];
+          r = __builtin_amdgcn_permlane32_swap(w0y, w1y, false, false);
+          w0y = r[0]; w1y = r[1];
+        }
+        *(uint4*)(yb + mt * rsy + coff + lane_y) = make_uint4(w0x, w0y, w1x, w1y);
+        if (STM == 2) __builtin_amdgcn_sched_barrier(0);  // one pixel row at a time: 32 interleaved silu' chains would not fit the register file
+      }
+      __builtin_amdgcn_sched_barrier(0);                 // keep the loads of the next (nt, k) group behind this one's stores
+      if (STM == 1) {
+        s1[nt * 4 + 2 * k] = t1[0]; s2[nt * 4 + 2 * k] = t2[0];
+        s1[nt * 4 + 2 * k + 1] = t1[1]; s2[nt * 4 + 2 * k + 1] = t2[1];
+      } else if (STM == 2) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          s1[nt * 4 + 2 * k + q] = t1[q];
+          s2[nt * 4 + 2 * k + q] = (t2[q] - gm[q] * t1[q]) * gr[q];     // sum a*dz*xhat over this lane's values
+        }
+      }
+    }
+  }
+  if (STM) {
+    // pixels -> lane 0 of each half-wave; waves -> LDS; one fp64 atomic pair per channel quad
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int o = 1; o < 32; o <<= 1) { s1[i] += __shfl_xor(s1[i], o, 64); s2[i] += __shfl_xor(s2[i], o, 64); }
+    float* sred = (float*)smem;                           // [wave][h][8][2]; the patch buffers are dead (last stage ended with a barrier)
+    if (pl == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        sred[((wave * 2 + h) * 8 + i) * 2] = s1[i];
+        sred[((wave * 2 + h) * 8 + i) * 2 + 1] = s2[i];
+      }
+    }
+    __syncthreads();
+    if (tid < 32) {
+      // tid -> (wn', h', i): quad index i = nt * 4 + q of wave column wn'
+      const int wn2 = tid >> 4, h2 = (tid >> 3) & 1, i = tid & 7;
+      const float a = sred[(((0 * 2 + wn2) * 2 + h2) * 8 + i) * 2] + sred[(((1 * 2 + wn2) * 2 + h2) * 8 + i) * 2];
+      const float b = sred[(((0 * 2 + wn2) * 2 + h2) * 8 + i) * 2 + 1] + sred[(((1 * 2 + wn2) * 2 + h2) * 8 + i) * 2 + 1];
+      const int ch = nb * C3_BN + wn2 * 64 + (i >> 2) * 32 + (i & 3) * 8 + 4 * h2;
+      double* dst = p.st_sums + ((long)img * 32 + ch / cpg) * 2;
+      atomicAdd(dst, (double)a);
+      atomicAdd(dst + 1, (double)b);
+    }
+  }
+}
+
+template <int TF, int STM>
+int launch3(const Conv3Params& p, hipStream_t st) {
+  auto kern = conv3_kernel<TF, STM>;
+  static std::atomic<unsigned long long> granted{0};     // dynamic-LDS cap raised once per (instantiation, device)
+  int dev = 0;
+  KDIP_HIP_CHECK(hipGetDevice(&dev));
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(granted.load(std::memory_order_acquire) & bit)) {
+    KDIP_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, c3_lds_bytes(TF)));
+    granted.fetch_or(bit, std::memory_order_release);
+  }
+  const long grid = (long)p.mtiles * p.nblkN;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((grid + 7) / 8 * 8)), dim3(256), c3_lds_bytes(TF), st, p);
+  return KDIP_OK;
+}
+
+}  // namespace
+
+bool conv3_eligible(DType dt, int ntaps, int H, int W, int Cin_pad, int Cout, long ldx, long ldy) {
+  return dt == DT_BF16 && ntaps == 9 && H % C3_TH == 0 && W % C3_TW == 0 && Cin_pad % 32 == 0 && Cin_pad <= C3_MAXCIN && Cout % C3_BN == 0 &&
+         ldx % 8 == 0 && ldy % 8 == 0;
+}
+
+int conv3_forward(hipStream_t st, const void* x, long ldx, int B, int H, int W, int Cin, const void* wp, const float* bias, int Cout,
+                  void* y, long ldy, const void* res, long ldr, const Conv3Fuse* fu, int cin_real) {
+  KDIP_REQUIRE(conv3_eligible(DT_BF16, 9, H, W, Cin, Cout, ldx, ldy), "conv3: shape not eligible (H=%d W=%d Cin=%d Cout=%d)", H, W, Cin, Cout);
+  KDIP_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)wp % 16) == 0 && ((uintptr_t)y % 16) == 0, "conv3: pointers must be 16-byte aligned");
+  KDIP_REQUIRE(!res || (ldr % 4 == 0 && (uintptr_t)res % 8 == 0), "conv3: residual must be 8-byte aligned");
+  KDIP_REQUIRE((long)B * H * W * ldx * 2 / 16 < (1L << 31), "conv3: input tensor too large for 32-bit vector offsets");
+  Conv3Params p{};
+  p.x = (const bf16_t*)x; p.ldx = ldx; p.wp = (const uint4*)wp; p.bias = bias; p.res = (const bf16_t*)res; p.ldr = ldr;
+  p.y = (bf16_t*)y; p.ldy = ldy; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+  p.ntilesN = Cout / 32; p.tilesX = W / C3_TW; p.tilesY = H / C3_TH; p.mtiles = B * p.tilesX * p.tilesY; p.nblkN = Cout / C3_BN;
+  int tf = 0, stm = 0;
+  if (fu) {
+    p.in_ups = fu->in_ups; p.res_ups = fu->res_ups;
+    tf = fu->tf; p.tf_coef = fu->tf_coef; p.tf_silu = fu->tf_silu; p.x2 = (const bf16_t*)fu->x2; p.ldx2 = fu->ldx2;
+    stm = fu->st_mode; p.st_silu = fu->st_silu; p.st_sums = fu->st_sums; p.st_x = (const bf16_t*)fu->st_x; p.st_ldx = fu->st_ldx;
+    p.st_coef = fu->st_coef; p.st_mr = fu->st_mr;
+  }
+  KDIP_REQUIRE(!(p.in_ups || p.res_ups) || (H % 2 == 0 && W % 2 == 0), "conv3: fused x2 upsample needs even H, W");
+  KDIP_REQUIRE(tf >= 0 && tf <= 2 && stm >= 0 && stm <= 2, "conv3: bad fusion modes");
+  // every GroupNorm in front of / behind a 3x3 conv of the UNet is followed by SiLU: the activation is compiled in (a
+  // run-time switch doubled the epilogue's register footprint: 170 spilled VGPRs)
+  KDIP_REQUIRE((tf == 0 || p.tf_silu) && (stm != 2 || p.st_silu), "conv3: the fused GroupNorm transforms include SiLU");
+  KDIP_REQUIRE(tf == 0 || ((uintptr_t)p.tf_coef % 16) == 0, "conv3: transform coefficients must be 16-byte aligned");
+  KDIP_REQUIRE(tf != 2 || (p.x2 && p.ldx2 % 8 == 0 && (uintptr_t)p.x2 % 16 == 0 && !p.in_ups), "conv3: GroupNorm-backward staging needs the GroupNorm input");
+  KDIP_REQUIRE(stm == 0 || ((Cout >> 5) % 4 == 0 && p.st_sums), "conv3: fused statistics need Cout / 32 to be a multiple of 4");
+  KDIP_REQUIRE(stm != 2 || (p.st_x && p.st_ldx % 4 == 0 && (uintptr_t)p.st_x % 8 == 0 && (uintptr_t)p.st_coef % 16 == 0 && (uintptr_t)p.st_mr % 8 == 0),
+               "conv3: backward statistics need the GroupNorm input / coefficients (aligned)");
+  if (g_prof_on) {
+    const double px = (double)B * H * W;
+    const int cr = cin_real > 0 ? cin_real : Cin;
+    prof_begin(st, PC_CONV3_128x128, 2.0 * px * cr * Cout * 9, px * (cr + Cout) * 2.0 + 9.0 * cr * Cout * 2.0, tf ? (tf == 1 ? "conv3_gnf" : "conv3_gnb") : "conv3", B, H, cr, Cout);
+  }
+  int rc;
+#define C3_GO(T, S) rc = launch3<T, S>(p, st)
+  if (tf == 0) { if (stm == 0) C3_GO(0, 0); else if (stm == 1) C3_GO(0, 1); else C3_GO(0, 2); }
+  else if (tf == 1) { if (stm == 0) C3_GO(1, 0); else if (stm == 1) C3_GO(1, 1); else C3_GO(1, 2); }
+  else { if (stm == 0) C3_GO(2, 0); else if (stm == 1) C3_GO(2, 1); else C3_GO(2, 2); }
+#undef C3_GO
+  prof_end(st);
+  if (rc) return rc;
+  KDIP_LAUNCH_CHECK();
+  return KDIP_OK;
+}
+
+}  // namespace kdip

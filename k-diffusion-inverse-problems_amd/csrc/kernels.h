@@ -27,6 +27,26 @@ int conv_debug_timing(void* buf, int H, int cin, int cout, int st_mode);   // -D
 void pack_conv_weight(DType dt, const float* w, int Cout, int Cin, int ntaps, int transpose_flip, int Cin_pad_out,
                       void* out);
 
+// ---- conv3.hip: second-generation bf16 3x3 conv for the large maps (W % 32 == 0, H % 8 == 0, Cout % 128 == 0), with the
+// preceding GroupNorm(+FiLM+SiLU) forward apply or GroupNorm backward apply fused into the input staging ---------------
+struct Conv3Fuse {
+  int in_ups = 0, res_ups = 0;       // input / residual are half-resolution tensors read at (y >> 1, x >> 1)
+  // staging transform of the input patch:
+  //   tf 1: A = silu?(a*x + b)                       tf_coef [B][Cin][2] = (a, b)        (gn_coef)
+  //   tf 2: A = a*dz - (k0 + k1*x2), dz = x * silu'?(a*x2 + b)   tf_coef [B][Cin][4] = (a, b, k0, k1)   (gn_bwd_coef); x2 = GroupNorm input
+  int tf = 0, tf_silu = 0;
+  const float* tf_coef = nullptr;
+  const void* x2 = nullptr; long ldx2 = 0;
+  // statistics of the OUTPUT accumulated in the epilogue (same meaning as ConvStats::mode 1 / 2)
+  int st_mode = 0, st_silu = 0;
+  double* st_sums = nullptr;
+  const void* st_x = nullptr; long st_ldx = 0;
+  const float* st_coef = nullptr; const float* st_mr = nullptr;
+};
+bool conv3_eligible(DType dt, int ntaps, int H, int W, int Cin_pad, int Cout, long ldx, long ldy);
+int conv3_forward(hipStream_t st, const void* x, long ldx, int B, int H, int W, int Cin, const void* wp, const float* bias, int Cout,
+                  void* y, long ldy, const void* res, long ldr, const Conv3Fuse* fu, int cin_real = 0);
+
 // ---- gemm.hip: strided batched GEMM  C[b] = alpha * A[b] (MxK) * B[b] (KxN) ----------------
 // element strides; batch index b = b1*nb2 + b2 with separate strides per level.
 struct BGemm {
