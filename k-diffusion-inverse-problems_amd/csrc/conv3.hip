@@ -23,6 +23,7 @@
 //   * epilogue: bias, residual (optionally read through a fused nearest x2 upsample), bf16 store, and the GroupNorm
 //     forward sums (mode 1) or backward sums (mode 2) of the OUTPUT accumulated per lane and combined once per block.
 #include <atomic>
+#include <type_traits>
 #include "common.h"
 #include "kernels.h"
 
@@ -35,10 +36,17 @@ constexpr int C3_PW = C3_TW + 2, C3_PH = C3_TH + 2, C3_NPIX = C3_PW * C3_PH;   /
 constexpr int C3_PIXB = 80;                               // LDS pixel pitch: 64 B of channels + 16 B pad
 constexpr int C3_ABUF = C3_NPIX * C3_PIXB;                // 27200 B per patch buffer
 constexpr int C3_BSLOT = 8192;                            // one weight stage: 2 k-steps x 4 n-tiles x 1 KiB
+constexpr int C3_NSLOT = 3;                               // weight ring: stage s+2 is in flight while stage s is consumed
 constexpr int C3_MAXV = (C3_NPIX * 4 + 255) / 256;        // staged 16-byte vectors per thread (6)
-constexpr int C3_MAXCIN = 512;                            // transform coefficient table: <= 512 input channels x 16 B
-constexpr int C3_TAB = 2 * C3_ABUF + 2 * C3_BSLOT;        // LDS offset of the table
-constexpr int c3_lds_bytes(int tf) { return C3_TAB + (tf == 0 ? 0 : (tf == 1 ? C3_MAXCIN * 8 : C3_MAXCIN * 16)); }   // 70784 / 74880 / 78976 B
+constexpr int C3_LDS = 2 * C3_ABUF + C3_NSLOT * C3_BSLOT; // 78976 B (+ 64 B dummy slot): two blocks per CU
+// The per-channel coefficients of the staging transform ride in the 16-byte PADS of the patch pixels (never touched by the
+// staging writes or the fragment reads): table slot j = pad of pixel j % 336 of patch buffer j / 336 -> 672 slots.
+// TF 1: slot = 2 channels x (a, b); TF 2: slot = 1 channel x (a, b, k0, k1).
+constexpr int C3_TABPIX = 336, C3_TABSLOTS = 2 * C3_TABPIX;
+constexpr int c3_max_cin(int tf) { return tf == 1 ? 2 * C3_TABSLOTS : (tf == 2 ? C3_TABSLOTS : (1 << 20)); }
+__device__ __forceinline__ int c3_tab_off(int slot) { return (slot / C3_TABPIX) * C3_ABUF + (slot % C3_TABPIX) * C3_PIXB + 64; }
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 struct Conv3Params {
   const bf16_t* x; long ldx;          // staged tensor (TF 0/1: the conv input or GroupNorm input; TF 2: dy of the GroupNorm output)
@@ -84,86 +92,98 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
   const int ty0 = trem / p.tilesX;
   const int y0 = ty0 * C3_TH, x0 = (trem - ty0 * p.tilesX) * C3_TW;
 
-  // ---- staging descriptors: vector v = tid + 256 i -> (halo pixel v >> 2, 16-byte channel group v & 3 = tid & 3)
-  int goff[C3_MAXV];                   // source offset in 16-byte units, -1 = zero fill
-  int goff2[TF == 2 ? C3_MAXV : 1];
+  // ---- staging descriptors: vector v = tid + 256 i -> (halo pixel v >> 2, 16-byte channel group v & 3 = tid & 3).
+  // Byte offsets are relative to the image (32 bits); padding / out-of-patch lanes read offset 0 and are zeroed when written,
+  // so every wave issues exactly the same number of loads (the K loop counts its outstanding loads by hand, see below).
+  const int Hs = p.in_ups ? p.H >> 1 : p.H, Ws = p.in_ups ? p.W >> 1 : p.W;
+  const bf16_t* const ximg = p.x + (long)img * Hs * Ws * p.ldx;
+  const bf16_t* const x2img = TF == 2 ? p.x2 + (long)img * Hs * Ws * p.ldx : p.x;       // same geometry as x (checked on the host)
+  unsigned goff[C3_MAXV];
+  unsigned zmask = 0;                  // bit i: vector i is zero fill (conv padding); bit 8 + i: vector i is outside the patch
 #pragma unroll
   for (int i = 0; i < C3_MAXV; ++i) {
     const int v = tid + i * 256, pix = v >> 2;
     const int hy = pix / C3_PW, hx = pix - hy * C3_PW;
     const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-    goff[i] = -1;
-    if (TF == 2) goff2[i] = -1;
-    if (pix < C3_NPIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
-      const long spix = p.in_ups ? ((long)img * (p.H >> 1) + (gy >> 1)) * (p.W >> 1) + (gx >> 1) : ((long)img * p.H + gy) * p.W + gx;
-      goff[i] = (int)(spix * (p.ldx >> 3)) + (tid & 3);
-      if (TF == 2) goff2[i] = (int)(spix * (p.ldx2 >> 3)) + (tid & 3);
+    goff[i] = (unsigned)((tid & 3) * 16);
+    if (pix >= C3_NPIX) zmask |= 0x101u << i;
+    else if (gy < 0 || gy >= p.H || gx < 0 || gx >= p.W) zmask |= 1u << i;
+    else {
+      const int spix = p.in_ups ? (gy >> 1) * Ws + (gx >> 1) : gy * Ws + gx;
+      goff[i] = (unsigned)((spix * (int)p.ldx + (tid & 3) * 8) * 2);
     }
   }
   const int nchunks = p.Cin >> 5;
-  // The patch of chunk c+1 is staged one 16-byte vector per thread per tap: vector i is requested at tap i of chunk c and
-  // transformed + written to the other patch buffer at tap i+1 (every stage ends with a barrier that also drains the
-  // loads, so the data is there); at most one vector (two for TF 2) is live, and the transform's VALU work is spread evenly
-  // under the MFMAs of six stages.  The per-channel coefficients live in an LDS table filled once per block.
-  uint4 sreg = make_uint4(0, 0, 0, 0), sreg2 = make_uint4(0, 0, 0, 0);
-  auto vec_load = [&](int c, int i) {
-    sreg = make_uint4(0, 0, 0, 0);
-    if (goff[i] >= 0) sreg = *(const uint4*)(p.x + (long)goff[i] * 8 + c * 32);
-    if (TF == 2) {
-      sreg2 = make_uint4(0, 0, 0, 0);
-      if (goff2[i] >= 0) sreg2 = *(const uint4*)(p.x2 + (long)goff2[i] * 8 + c * 32);
-    }
+
+  // ---- staging of chunk c+1 under the MFMAs of chunk c.  Vector i is requested at tap i (i = 0..5) and transformed +
+  // written to the other patch buffer at tap i+3: three stage times (~1.5k cycles) cover the HBM latency.  The loads are
+  // inline asm so that hipcc neither waits for them itself (next to LDS-DMA traffic it would drain the whole queue with
+  // vmcnt(0)) nor touches their destination registers before the counted wait at the top of the consuming stage.
+  u32x4 sa[3], sb[TF == 2 ? 3 : 1];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) sa[j] = (u32x4){0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < (TF == 2 ? 3 : 1); ++j) sb[j] = (u32x4){0, 0, 0, 0};
+  auto vec_load_asm = [&](int cbytes, int i) {      // chunk byte offset (c * 64), vector i -> register set i % 3
+    const unsigned off = goff[i] + (unsigned)cbytes;
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(sa[i % 3]) : "v"(off), "s"(ximg) : "memory");
+    if (TF == 2) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(sb[i % 3]) : "v"(off), "s"(x2img) : "memory");
   };
-  auto vec_write = [&](int c, int i) {
-    const int v = tid + i * 256, pix = v >> 2;
-    if (pix >= C3_NPIX) return;
-    uint4 o = sreg;
+  auto transform = [&](int c, int i, uint4 o, uint4 o2) -> uint4 {
     if (TF == 1) {
-      const float4* tab = (const float4*)(smem + C3_TAB) + (c * 32 + (tid & 3) * 8) / 2;    // (a, b) pairs: 2 channels per float4
+      const int slot = (c * 32 + (tid & 3) * 8) >> 1;                       // 4 consecutive slots: (a, b) of 2 channels each
+      const unsigned char* tab = smem + c3_tab_off(slot);
       float f[8];
       unpack16<bf16_t>(o, f);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float4 k = tab[j];
+        const float4 k = *(const float4*)(tab + j * C3_PIXB);
         const float z0 = k.x * f[2 * j] + k.y, z1 = k.z * f[2 * j + 1] + k.w;
         f[2 * j] = silu_fast(z0);
         f[2 * j + 1] = silu_fast(z1);
       }
       o = pack16<bf16_t>(f);
-      if (goff[i] < 0) o = make_uint4(0, 0, 0, 0);          // conv zero padding applies to the ACTIVATED tensor
     } else if (TF == 2) {
-      const float4* tab = (const float4*)(smem + C3_TAB) + (c * 32 + (tid & 3) * 8);        // (a, b, k0, k1) per channel
+      const int slot = c * 32 + (tid & 3) * 8;                              // 8 consecutive slots: (a, b, k0, k1) per channel
+      const unsigned char* tab = smem + c3_tab_off(slot);
       float fd[8], fx[8];
       unpack16<bf16_t>(o, fd);
-      unpack16<bf16_t>(sreg2, fx);
+      unpack16<bf16_t>(o2, fx);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float4 k = tab[e];
+        const float4 k = *(const float4*)(tab + e * C3_PIXB);
         const float z = k.x * fx[e] + k.y;
         const float dz = fd[e] * silu_grad_fast(z);
         fd[e] = k.x * dz - (k.z + k.w * fx[e]);
       }
       o = pack16<bf16_t>(fd);
-      if (goff[i] < 0) o = make_uint4(0, 0, 0, 0);
     }
-    *(uint4*)(smem + (c & 1) * C3_ABUF + pix * C3_PIXB + (tid & 3) * 16) = o;
+    if ((zmask >> i) & 1) o = make_uint4(0, 0, 0, 0);      // conv zero padding applies to the TRANSFORMED tensor
+    return o;
   };
-  if (TF == 1) {
-    const float2* src = (const float2*)(p.tf_coef + (long)img * p.Cin * 2);
-    for (int ch = tid; ch < p.Cin; ch += 256) ((float2*)(smem + C3_TAB))[ch] = src[ch];
-  } else if (TF == 2) {
-    const float4* src = (const float4*)(p.tf_coef + (long)img * p.Cin * 4);
-    for (int ch = tid; ch < p.Cin; ch += 256) ((float4*)(smem + C3_TAB))[ch] = src[ch];
-  }
+  auto vec_store = [&](int c, int i, uint4 o) {      // branch free: lanes outside the patch (vector 5, tid >= 80) write a dummy slot
+    const int pix = (tid + i * 256) >> 2;
+    int addr = (c & 1) * C3_ABUF + pix * C3_PIXB + (tid & 3) * 16;
+    if (i * 256 + 255 >= C3_NPIX * 4) addr = ((zmask >> (8 + i)) & 1) ? C3_LDS + (tid & 3) * 16 : addr;
+    *(uint4*)(smem + addr) = o;
+  };
 
-  // ---- weight stream: stage (chunk c, tap t) = k-steps 2c, 2c+1 of tap t, n-tiles 4 nb .. 4 nb + 3
-  const long kStride = (long)p.ntilesN * 64, tapStride = (long)(p.Cin >> 4) * kStride;
-  const uint4* wthr = p.wp + (long)nb * 256 + tid;       // this thread's 16 bytes inside a k-step row
+  // ---- weight stream: stage (chunk c, tap t) = k-steps 2c, 2c+1 of tap t, n-tiles 4 nb .. 4 nb + 3, ring slot t % 3
+  // (9 taps per chunk: the slot of stage 9c + t is t % 3)
+  // The DMAs are inline asm as well: next to a builtin LDS-DMA hipcc drains the whole memory queue (vmcnt(0)) in front of
+  // the next ds_read of the same LDS object, i.e. once per stage.  M0 (the LDS destination base) is saved / restored around
+  // the two transfers; address = wave-uniform stage base (SGPR pair) + this thread's constant 32-bit byte offset.
+  const long kStride = (long)p.ntilesN * 64, tapStride = (long)(p.Cin >> 4) * kStride;     // in 16-byte units
+  const unsigned w_voff = (unsigned)((nb * 256 + tid) * 16);
+  const unsigned lds_b = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem + 2 * C3_ABUF + wave * 1024;
   auto dma_b = [&](int c, int tap, int slot) {
-    const uint4* g = wthr + tap * tapStride + (long)(2 * c) * kStride;
-    unsigned char* l = smem + 2 * C3_ABUF + slot * C3_BSLOT + wave * 1024;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + kStride), (__attribute__((address_space(3))) void*)(l + 4096), 16, 0, 0);
+    const uint4* g0 = p.wp + tap * tapStride + (long)(2 * c) * kStride;
+    const uint4* g1 = g0 + kStride;
+    const unsigned l0 = lds_b + slot * C3_BSLOT, l1 = l0 + 4096;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                 "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(w_voff), "s"(g0), "s"(g1), "s"(l0), "s"(l1) : "memory");
   };
 
   f32x16 acc[4][2];
@@ -174,31 +194,61 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-  // ---- prologue: weight stage 0 in flight, then the whole first patch (coefficient table first: one barrier)
+  // ---- prologue: weight stages 0 and 1 in flight; coefficient table -> pads; the whole first patch (compiler-managed loads)
   dma_b(0, 0, 0);
-  if (TF) __syncthreads();
+  dma_b(0, 1, 1);
+  if (TF == 1) {
+    const float4* src = (const float4*)(p.tf_coef + (long)img * p.Cin * 2);
+    for (int j = tid; j < p.Cin / 2; j += 256) *(float4*)(smem + c3_tab_off(j)) = src[j];
+    __syncthreads();
+  } else if (TF == 2) {
+    const float4* src = (const float4*)(p.tf_coef + (long)img * p.Cin * 4);
+    for (int j = tid; j < p.Cin; j += 256) *(float4*)(smem + c3_tab_off(j)) = src[j];
+    __syncthreads();
+  }
 #pragma unroll
   for (int i = 0; i < C3_MAXV; ++i) {
-    vec_load(0, i);
-    vec_write(0, i);
+    const uint4 o = *(const uint4*)((const char*)ximg + goff[i]);
+    uint4 o2 = make_uint4(0, 0, 0, 0);
+    if (TF == 2) o2 = *(const uint4*)((const char*)x2img + goff[i]);
+    vec_store(0, i, transform(0, i, o, o2));
   }
-  __syncthreads();
 
   const int a_lane = (wm * 4 * C3_PW + (lane & 31)) * C3_PIXB + (lane >> 5) * 16;   // + (mt + ty) * PW * PIXB + tx * PIXB + ks * 32
   const int b_lane = 2 * C3_ABUF + (wn * 2 * 64 + lane) * 16;                       // + slot * BSLOT + (ks * 4 + nt) * 1024
+  constexpr int NV = TF == 2 ? 2 : 1;                  // staging loads per vector
 
+  // Per stage (chunk c, tap t), every wave issues, in this order: 2 weight DMAs (stage s+2), then NV staging loads if t < 6.
+  // At the top of stage s the weights of stage s (issued at s-2) and the staging vector written in this stage (issued at s-3)
+  // must have landed; still allowed in flight: the staging loads of s-2 and everything of s-1
+  //   -> vmcnt(2 + nv(t-1) + nv(t-2)), nv(t) = NV for t < 6 else 0 (taps wrap within the 9-tap chunk).
+  // The raw s_barrier that follows (a) publishes every wave's landed DMA of stage s and the patch writes of earlier stages
+  // (lgkmcnt(0) in the same wait), (b) guarantees all waves are done reading ring slot (s-1) % 3 before it is refilled.
+#define C3_NVT(t) (((t) + 9) % 9 < 6 ? NV : 0)
   for (int c = 0; c < nchunks; ++c) {
     const unsigned char* ab = smem + (c & 1) * C3_ABUF + a_lane;
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int slot = (c + tap) & 1;               // stage index c * 9 + tap, parity = (c + tap) & 1
+    const int cn = c + 1 < nchunks ? c + 1 : c;                 // last chunk: redundant re-loads keep the counts uniform (results unused)
+    auto stage = [&](auto tapc) {
+      constexpr int tap = decltype(tapc)::value;
+      if (TF == 2)
+        asm volatile("s_waitcnt vmcnt(%6) lgkmcnt(0)" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sa[2]), "+v"(sb[0]), "+v"(sb[TF == 2 ? 1 : 0]), "+v"(sb[TF == 2 ? 2 : 0])
+                     : "n"(2 + C3_NVT(tap - 1) + C3_NVT(tap - 2)) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(%3) lgkmcnt(0)" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sa[2]) : "n"(2 + C3_NVT(tap - 1) + C3_NVT(tap - 2)) : "memory");
+      __builtin_amdgcn_s_barrier();
       {
-        const int tn = tap == 8 ? 0 : tap + 1, cn = tap == 8 ? c + 1 : c;
-        if (cn < nchunks) dma_b(cn, tn, slot ^ 1);
+        const int t2 = tap + 2 >= 9 ? tap + 2 - 9 : tap + 2;
+        const int c2 = tap + 2 >= 9 ? cn : c;
+        dma_b(c2, t2, t2 % 3);
       }
-      if (tap >= 1 && tap <= C3_MAXV && c + 1 < nchunks) vec_write(c + 1, tap - 1);
-      if (tap < C3_MAXV && c + 1 < nchunks) vec_load(c + 1, tap);
-      const unsigned char* bb = smem + b_lane + slot * C3_BSLOT;
+      if (tap >= 3) {               // (last chunk: the other buffer is dead, the redundant write is harmless and keeps the stage branch free)
+        const int i = tap - 3;
+        const uint4 o = __builtin_bit_cast(uint4, sa[i % 3]);
+        const uint4 o2 = TF == 2 ? __builtin_bit_cast(uint4, sb[TF == 2 ? i % 3 : 0]) : make_uint4(0, 0, 0, 0);
+        vec_store(c + 1, i, transform(cn, i, o, o2));
+      }
+      if (tap < C3_MAXV) vec_load_asm(cn * 64, tap);
+      const unsigned char* bb = smem + b_lane + (tap % 3) * C3_BSLOT;
       const int toff = ((tap / 3) * C3_PW + (tap % 3)) * C3_PIXB;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -212,9 +262,15 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma_bf16(bf[nt], af[mt], acc[mt][nt]);
       }
-      __syncthreads();
-    }
+    };
+    stage(std::integral_constant<int, 0>{}); stage(std::integral_constant<int, 1>{}); stage(std::integral_constant<int, 2>{});
+    stage(std::integral_constant<int, 3>{}); stage(std::integral_constant<int, 4>{}); stage(std::integral_constant<int, 5>{});
+    stage(std::integral_constant<int, 6>{}); stage(std::integral_constant<int, 7>{}); stage(std::integral_constant<int, 8>{});
   }
+#undef C3_NVT
+  // drain the redundant tail loads / DMAs before their registers and LDS are reused; all waves past their last fragment reads
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
 
   // ---- epilogue (no LDS traffic until the statistics combine).  Addresses = wave-uniform 64-bit row bases + one 32-bit
   // per-lane byte offset per tensor (the loads / stores use the saddr + voffset form: no 64-bit vector arithmetic).
@@ -362,18 +418,18 @@ int launch3(const Conv3Params& p, hipStream_t st) {
   KDIP_HIP_CHECK(hipGetDevice(&dev));
   const unsigned long long bit = 1ull << (dev & 63);
   if (!(granted.load(std::memory_order_acquire) & bit)) {
-    KDIP_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, c3_lds_bytes(TF)));
+    KDIP_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS + 64));
     granted.fetch_or(bit, std::memory_order_release);
   }
   const long grid = (long)p.mtiles * p.nblkN;
-  hipLaunchKernelGGL(kern, dim3((unsigned)((grid + 7) / 8 * 8)), dim3(256), c3_lds_bytes(TF), st, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)((grid + 7) / 8 * 8)), dim3(256), C3_LDS + 64, st, p);
   return KDIP_OK;
 }
 
 }  // namespace
 
 bool conv3_eligible(DType dt, int ntaps, int H, int W, int Cin_pad, int Cout, long ldx, long ldy) {
-  return dt == DT_BF16 && ntaps == 9 && H % C3_TH == 0 && W % C3_TW == 0 && Cin_pad % 32 == 0 && Cin_pad <= C3_MAXCIN && Cout % C3_BN == 0 &&
+  return dt == DT_BF16 && ntaps == 9 && H % C3_TH == 0 && W % C3_TW == 0 && Cin_pad % 32 == 0 && Cout % C3_BN == 0 &&
          ldx % 8 == 0 && ldy % 8 == 0;
 }
 
@@ -382,7 +438,6 @@ int conv3_forward(hipStream_t st, const void* x, long ldx, int B, int H, int W, 
   KDIP_REQUIRE(conv3_eligible(DT_BF16, 9, H, W, Cin, Cout, ldx, ldy), "conv3: shape not eligible (H=%d W=%d Cin=%d Cout=%d)", H, W, Cin, Cout);
   KDIP_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)wp % 16) == 0 && ((uintptr_t)y % 16) == 0, "conv3: pointers must be 16-byte aligned");
   KDIP_REQUIRE(!res || (ldr % 4 == 0 && (uintptr_t)res % 8 == 0), "conv3: residual must be 8-byte aligned");
-  KDIP_REQUIRE((long)B * H * W * ldx * 2 / 16 < (1L << 31), "conv3: input tensor too large for 32-bit vector offsets");
   Conv3Params p{};
   p.x = (const bf16_t*)x; p.ldx = ldx; p.wp = (const uint4*)wp; p.bias = bias; p.res = (const bf16_t*)res; p.ldr = ldr;
   p.y = (bf16_t*)y; p.ldy = ldy; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
@@ -400,7 +455,9 @@ int conv3_forward(hipStream_t st, const void* x, long ldx, int B, int H, int W, 
   // run-time switch doubled the epilogue's register footprint: 170 spilled VGPRs)
   KDIP_REQUIRE((tf == 0 || p.tf_silu) && (stm != 2 || p.st_silu), "conv3: the fused GroupNorm transforms include SiLU");
   KDIP_REQUIRE(tf == 0 || ((uintptr_t)p.tf_coef % 16) == 0, "conv3: transform coefficients must be 16-byte aligned");
-  KDIP_REQUIRE(tf != 2 || (p.x2 && p.ldx2 % 8 == 0 && (uintptr_t)p.x2 % 16 == 0 && !p.in_ups), "conv3: GroupNorm-backward staging needs the GroupNorm input");
+  KDIP_REQUIRE(tf != 2 || (p.x2 && p.ldx2 == ldx && (uintptr_t)p.x2 % 16 == 0 && !p.in_ups), "conv3: GroupNorm-backward staging needs the GroupNorm input in the layout of x");
+  KDIP_REQUIRE(Cin <= c3_max_cin(tf), "conv3: too many input channels (%d) for the staging-transform table", Cin);
+  KDIP_REQUIRE((long)H * W * ldx * 2 < (1L << 31), "conv3: image too large for 32-bit staging offsets");
   KDIP_REQUIRE(stm == 0 || ((Cout >> 5) % 4 == 0 && p.st_sums), "conv3: fused statistics need Cout / 32 to be a multiple of 4");
   KDIP_REQUIRE(stm != 2 || (p.st_x && p.st_ldx % 4 == 0 && (uintptr_t)p.st_x % 8 == 0 && (uintptr_t)p.st_coef % 16 == 0 && (uintptr_t)p.st_mr % 8 == 0),
                "conv3: backward statistics need the GroupNorm input / coefficients (aligned)");
