@@ -177,6 +177,8 @@ int kdip_test_groupnorm(void* stream, int dtype, const float* x_nchw_dev, int B,
  * matching (H, real Cin, Cout, fused-statistics mode) writes per-block phase timestamps (100 MHz ticks: start, first patch
  * staged, K loop done, end, + 3 epilogue sub-phases) to dev_buf[grid][8] (uint64).  dev_buf = NULL switches it off.  tools/conv_phases.py. */
 int kdip_debug_conv_timing(void* dev_buf, int H, int cin, int cout, int st_mode);
+/* Same for csrc/conv3.hip (-DC3_TIMING=1): dev_buf[grid][8] = start, first patch staged, K loop done, end (100 MHz ticks), XCC id. */
+int kdip_debug_conv3_timing(void* dev_buf);
 
 #ifdef __cplusplus
 }

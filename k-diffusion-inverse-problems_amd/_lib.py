@@ -57,6 +57,7 @@ SIGNATURES = {
     "kdip_profile_dump": (C.c_int, [C.c_char_p]),
     "kdip_debug_conv_timing": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, C.c_int]),
     "kdip_test_conv": (C.c_int, [VP, C.c_int, C.c_int, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, C.c_int, C.c_int, VP, C.c_int]),
+    "kdip_debug_conv3_timing": (C.c_int, [VP]),
     "kdip_test_conv3": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, C.c_int, C.c_int, C.c_int, VP, VP, C.c_int, C.c_int,
                                   C.c_int, VP, VP, VP, VP, VP, C.c_int, VP]),
     "kdip_test_groupnorm": (C.c_int, [VP, C.c_int, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, VP, C.c_int, VP, VP, VP]),

@@ -47,6 +47,22 @@ constexpr int c3_max_cin(int tf) { return tf == 1 ? 2 * C3_TABSLOTS : (tf == 2 ?
 __device__ __forceinline__ int c3_tab_off(int slot) { return (slot / C3_TABPIX) * C3_ABUF + (slot % C3_TABPIX) * C3_PIXB + 64; }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef C3_ABL_NOATOM
+#define C3_ABL_NOATOM 0        // timing ablations (tools/): statistics atomics off / staging transform math off / no epilogue
+#endif
+#ifndef C3_ABL_NOTF
+#define C3_ABL_NOTF 0
+#endif
+#ifndef C3_ABL_NOEPI
+#define C3_ABL_NOEPI 0
+#endif
+#ifndef C3_TIMING
+#define C3_TIMING 0            // diagnostic build: per-block phase stamps (100 MHz) into the buffer set by conv3_debug_timing
+#endif
+#ifndef C3_STRICT_LGKM
+#define C3_STRICT_LGKM 0       // 1: drain the LDS queue in front of every stage barrier (validation builds)
+#endif
 
 struct Conv3Params {
   const bf16_t* x; long ldx;          // staged tensor (TF 0/1: the conv input or GroupNorm input; TF 2: dy of the GroupNorm output)
@@ -58,6 +74,7 @@ struct Conv3Params {
   int B, H, W, Cin, Cout;
   int ntilesN, tilesX, tilesY, mtiles, nblkN;
   int in_ups, res_ups;
+  unsigned long long* dbg;            // C3_TIMING builds: [grid][8] stamps (start, first patch staged, K loop done, end) + XCC id
   const float* tf_coef;               // TF 1: [B][Cin][2] (a, b); TF 2: [B][Cin][4] (a, b, k0, k1)
   int tf_silu;
   int st_silu;
@@ -67,6 +84,13 @@ struct Conv3Params {
   const float* st_mr;                 // mode 2: [B][32][2]
 };
 
+unsigned long long* g_c3_dbg = nullptr;
+#if C3_TIMING
+#define C3_STAMP(i) do { if (p.dbg && threadIdx.x == 0) p.dbg[(long)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define C3_STAMP(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ f32x16 mfma_bf16(const uint4& a, const uint4& b, const f32x16& c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
@@ -75,7 +99,7 @@ __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w <<
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
 // TF: staging transform (0 none, 1 GroupNorm forward apply, 2 GroupNorm backward apply); STM: statistics mode of the output
-template <int TF, int STM>
+template <int TF, int STM, bool RES>
 __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -86,6 +110,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
   const int xq = ntiles >> 3, xr = ntiles & 7, xcd = blockIdx.x & 7, xj = blockIdx.x >> 3;
   const int bid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xj;
   if (xj >= xq + (xcd < xr ? 1 : 0)) return;
+  C3_STAMP(0);
   const int mtile = bid / p.nblkN, nb = bid - mtile * p.nblkN;
   const int tpi = p.tilesX * p.tilesY;
   const int img = mtile / tpi, trem = mtile - img * tpi;
@@ -139,8 +164,8 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
       for (int j = 0; j < 4; ++j) {
         const float4 k = *(const float4*)(tab + j * C3_PIXB);
         const float z0 = k.x * f[2 * j] + k.y, z1 = k.z * f[2 * j + 1] + k.w;
-        f[2 * j] = silu_fast(z0);
-        f[2 * j + 1] = silu_fast(z1);
+        f[2 * j] = C3_ABL_NOTF ? z0 : silu_fast(z0);
+        f[2 * j + 1] = C3_ABL_NOTF ? z1 : silu_fast(z1);
       }
       o = pack16<bf16_t>(f);
     } else if (TF == 2) {
@@ -186,13 +211,22 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
                  : "=&s"(keep) : "v"(w_voff), "s"(g0), "s"(g1), "s"(l0), "s"(l1) : "memory");
   };
 
+  // accumulators start at the bias (lane (pixel, h) owns channels nt*32 + 8q + 4h + j in registers 4q + j): no bias pass later
   f32x16 acc[4][2];
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
+  {
+    const int hb = lane >> 5;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+      for (int q = 0; q < 4; ++q) {
+        float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) bq = *(const float4*)(p.bias + nb * C3_BN + wn * 64 + nt * 32 + 8 * q + 4 * hb);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          acc[mt][nt][4 * q + 0] = bq.x; acc[mt][nt][4 * q + 1] = bq.y; acc[mt][nt][4 * q + 2] = bq.z; acc[mt][nt][4 * q + 3] = bq.w;
+        }
+      }
+  }
 
   // ---- prologue: weight stages 0 and 1 in flight; coefficient table -> pads; the whole first patch (compiler-managed loads)
   dma_b(0, 0, 0);
@@ -214,6 +248,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
     vec_store(0, i, transform(0, i, o, o2));
   }
 
+  C3_STAMP(1);
   const int a_lane = (wm * 4 * C3_PW + (lane & 31)) * C3_PIXB + (lane >> 5) * 16;   // + (mt + ty) * PW * PIXB + tx * PIXB + ks * 32
   const int b_lane = 2 * C3_ABUF + (wn * 2 * 64 + lane) * 16;                       // + slot * BSLOT + (ks * 4 + nt) * 1024
   constexpr int NV = TF == 2 ? 2 : 1;                  // staging loads per vector
@@ -230,11 +265,18 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
     const int cn = c + 1 < nchunks ? c + 1 : c;                 // last chunk: redundant re-loads keep the counts uniform (results unused)
     auto stage = [&](auto tapc) {
       constexpr int tap = decltype(tapc)::value;
-      if (TF == 2)
-        asm volatile("s_waitcnt vmcnt(%6) lgkmcnt(0)" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sa[2]), "+v"(sb[0]), "+v"(sb[TF == 2 ? 1 : 0]), "+v"(sb[TF == 2 ? 2 : 0])
-                     : "n"(2 + C3_NVT(tap - 1) + C3_NVT(tap - 2)) : "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(%3) lgkmcnt(0)" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sa[2]) : "n"(2 + C3_NVT(tap - 1) + C3_NVT(tap - 2)) : "memory");
+      // lgkmcnt(0) (the patch writes of taps 3..8 visible to the other waves) is only needed before the chunk's first stage;
+      // draining the LDS queue in front of every barrier exposed the latency of the fragment reads hipcc hoists there
+      constexpr bool LG = tap == 0 || C3_STRICT_LGKM;
+      if (TF == 2) {
+        if (LG) asm volatile("s_waitcnt vmcnt(%6) lgkmcnt(0)" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sa[2]), "+v"(sb[0]), "+v"(sb[TF == 2 ? 1 : 0]), "+v"(sb[TF == 2 ? 2 : 0])
+                         : "n"(2 + C3_NVT(tap - 1) + C3_NVT(tap - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%6)" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sa[2]), "+v"(sb[0]), "+v"(sb[TF == 2 ? 1 : 0]), "+v"(sb[TF == 2 ? 2 : 0])
+                          : "n"(2 + C3_NVT(tap - 1) + C3_NVT(tap - 2)) : "memory");
+      } else {
+        if (LG) asm volatile("s_waitcnt vmcnt(%3) lgkmcnt(0)" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sa[2]) : "n"(2 + C3_NVT(tap - 1) + C3_NVT(tap - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%3)" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sa[2]) : "n"(2 + C3_NVT(tap - 1) + C3_NVT(tap - 2)) : "memory");
+      }
       __builtin_amdgcn_s_barrier();
       {
         const int t2 = tap + 2 >= 9 ? tap + 2 - 9 : tap + 2;
@@ -247,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
         const uint4 o2 = TF == 2 ? __builtin_bit_cast(uint4, sb[TF == 2 ? i % 3 : 0]) : make_uint4(0, 0, 0, 0);
         vec_store(c + 1, i, transform(cn, i, o, o2));
       }
-      if (tap < C3_MAXV) vec_load_asm(cn * 64, tap);
+      if (tap < C3_MAXV) vec_load_asm(cn * 64, tap);      // (last chunk: re-reads chunk c, L2-hot, results unused)
       const unsigned char* bb = smem + b_lane + (tap % 3) * C3_BSLOT;
       const int toff = ((tap / 3) * C3_PW + (tap % 3)) * C3_PIXB;
 #pragma unroll
@@ -272,30 +314,61 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
 
+  C3_STAMP(2);
+  if (C3_ABL_NOEPI) {     // timing ablation: keep the accumulators live, skip the epilogue
+    float t = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[mt][nt][r];
+    if (t == 12345.678f) p.y[0] = (bf16_t)1;
+    return;
+  }
   // ---- epilogue (no LDS traffic until the statistics combine).  Addresses = wave-uniform 64-bit row bases + one 32-bit
-  // per-lane byte offset per tensor (the loads / stores use the saddr + voffset form: no 64-bit vector arithmetic).
+  // per-lane byte offset per tensor (saddr + voffset loads / stores: no 64-bit vector arithmetic).  A lane owns, for its pixel,
+  // channel quads 8q + 4h + {0..3} of each n-tile; residual / GroupNorm-input rows are fetched up front as 16-byte vectors in
+  // the STORE layout (lane h: channels 16k + 8h .. +7) -- 32 contiguous bytes per pixel per instruction, all 16 loads in flight
+  // at once -- and brought to the accumulator layout with the inverse of the store's v_permlane32_swap pairing.
   const int h = lane >> 5, pl = lane & 31;
   const int cpg = p.Cout >> 5;
   const int nbase = nb * C3_BN + wn * 64;                 // first channel of this wave
   const int row0 = y0 + wm * 4;                           // first pixel row of this wave
-  float s1[8], s2[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
   char* const yb = (char*)(p.y + ((long)img * p.H + row0) * p.W * p.ldy + nbase);
   const unsigned rsy = (unsigned)(p.W * p.ldy * 2), lane_y = (unsigned)(((x0 + pl) * p.ldy + 8 * h) * 2);
-  const int Hr = p.res_ups ? p.H >> 1 : p.H, Wr = p.res_ups ? p.W >> 1 : p.W;
-  const char* const rb = (const char*)(p.res + (long)img * Hr * Wr * p.ldr + nbase);
-  const unsigned rsr = (unsigned)(Wr * p.ldr * 2), lane_r = (unsigned)((((p.res_ups ? (x0 + pl) >> 1 : x0 + pl)) * p.ldr + 4 * h) * 2);
-  const char* const xb = (const char*)(p.st_x + ((long)img * p.H + row0) * p.W * p.st_ldx + nbase);
-  const unsigned rsx = (unsigned)(p.W * p.st_ldx * 2), lane_x = (unsigned)(((x0 + pl) * p.st_ldx + 4 * h) * 2);
+  uint4 aux[4][2][2];                                     // [mt][nt][k]: residual (RES) or GroupNorm input (STM 2) vectors
+  if (RES) {
+    const int Hr = p.res_ups ? p.H >> 1 : p.H, Wr = p.res_ups ? p.W >> 1 : p.W;
+    const char* const rb = (const char*)(p.res + (long)img * Hr * Wr * p.ldr + nbase);
+    const unsigned rsr = (unsigned)(Wr * p.ldr * 2), lane_r = (unsigned)((((p.res_ups ? (x0 + pl) >> 1 : x0 + pl)) * p.ldr + 8 * h) * 2);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const char* r = rb + (unsigned)(p.res_ups ? (row0 + mt) >> 1 : row0 + mt) * rsr + lane_r;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) aux[mt][nt][k] = *(const uint4*)(r + (nt * 32 + 16 * k) * 2);
+    }
+  } else if (STM == 2) {
+    const char* const xb = (const char*)(p.st_x + ((long)img * p.H + row0) * p.W * p.st_ldx + nbase);
+    const unsigned rsx = (unsigned)(p.W * p.st_ldx * 2), lane_x = (unsigned)(((x0 + pl) * p.st_ldx + 8 * h) * 2);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) aux[mt][nt][k] = *(const uint4*)(xb + mt * rsx + lane_x + (nt * 32 + 16 * k) * 2);
+  }
+  float ss[16];                                           // [0..7]: sum 1 per (nt, quad), [8..15]: sum 2
+#pragma unroll
+  for (int i = 0; i < 16; ++i) ss[i] = 0.f;
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int cq = nbase + nt * 32 + 16 * k + 4 * h;    // quad 2k: channels cq .. cq+3; quad 2k+1: cq+8 .. cq+11
       const unsigned coff = (unsigned)((nt * 32 + 16 * k) * 2);
-      float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
-      if (p.bias) { b0 = *(const float4*)(p.bias + cq); b1 = *(const float4*)(p.bias + cq + 8); }
       float4 ka[4];                                       // mode 2: (a, b) of the 8 channels
       float gm[2], gr[2];
       if (STM == 2) {
@@ -307,53 +380,41 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
           gm[q] = m.x; gr[q] = m.y;
         }
       }
-      uint2 rr[4][2], xx[4][2];
-      if (p.res) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-          const char* r = rb + (unsigned)(p.res_ups ? (row0 + mt) >> 1 : row0 + mt) * rsr + coff;
-          rr[mt][0] = *(const uint2*)(r + lane_r);
-          rr[mt][1] = *(const uint2*)(r + lane_r + 16);
-        }
-      }
-      if (STM == 2) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-          const char* r = xb + mt * rsx + coff;
-          xx[mt][0] = *(const uint2*)(r + lane_x);
-          xx[mt][1] = *(const uint2*)(r + lane_x + 16);
-        }
-      }
       float t1[2] = {0.f, 0.f}, t2[2] = {0.f, 0.f};
+      f32x2 t1v[2] = {{0.f, 0.f}, {0.f, 0.f}}, t2v[2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         float v[8];
-        v[0] = acc[mt][nt][8 * k + 0] + b0.x; v[1] = acc[mt][nt][8 * k + 1] + b0.y;
-        v[2] = acc[mt][nt][8 * k + 2] + b0.z; v[3] = acc[mt][nt][8 * k + 3] + b0.w;
-        v[4] = acc[mt][nt][8 * k + 4] + b1.x; v[5] = acc[mt][nt][8 * k + 5] + b1.y;
-        v[6] = acc[mt][nt][8 * k + 6] + b1.z; v[7] = acc[mt][nt][8 * k + 7] + b1.w;
-        if (p.res) {
-          v[0] += bf_lo(rr[mt][0].x); v[1] += bf_hi(rr[mt][0].x); v[2] += bf_lo(rr[mt][0].y); v[3] += bf_hi(rr[mt][0].y);
-          v[4] += bf_lo(rr[mt][1].x); v[5] += bf_hi(rr[mt][1].x); v[6] += bf_lo(rr[mt][1].y); v[7] += bf_hi(rr[mt][1].y);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = acc[mt][nt][8 * k + e];
+        uint32_t u0 = 0, u1 = 0, u2 = 0, u3 = 0;          // aux in the accumulator layout: (u0, u1) = quad 2k, (u2, u3) = quad 2k+1
+        if (RES || STM == 2) {
+          const uint4 a4 = aux[mt][nt][k];
+          auto r = __builtin_amdgcn_permlane32_swap(a4.x, a4.z, false, false);
+          u0 = r[0]; u2 = r[1];
+          r = __builtin_amdgcn_permlane32_swap(a4.y, a4.w, false, false);
+          u1 = r[0]; u3 = r[1];
+        }
+        if (RES) {
+          v[0] += bf_lo(u0); v[1] += bf_hi(u0); v[2] += bf_lo(u1); v[3] += bf_hi(u1);
+          v[4] += bf_lo(u2); v[5] += bf_hi(u2); v[6] += bf_lo(u3); v[7] += bf_hi(u3);
         }
         uint32_t w0x = pack_bf16x2(v[0], v[1]), w0y = pack_bf16x2(v[2], v[3]);
         uint32_t w1x = pack_bf16x2(v[4], v[5]), w1y = pack_bf16x2(v[6], v[7]);
-        if (STM == 1) {     // statistics of the stored (rounded) values
-          const float r0 = bf_lo(w0x), r1 = bf_hi(w0x), r2 = bf_lo(w0y), r3 = bf_hi(w0y);
-          const float r4 = bf_lo(w1x), r5 = bf_hi(w1x), r6 = bf_lo(w1y), r7 = bf_hi(w1y);
-          t1[0] += (r0 + r1) + (r2 + r3); t2[0] += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
-          t1[1] += (r4 + r5) + (r6 + r7); t2[1] += (r4 * r4 + r5 * r5) + (r6 * r6 + r7 * r7);
+        if (STM == 1) {     // statistics of the fp32 values (before the bf16 rounding of the store), two lanes of packed fp32 math
+          t1v[0] += (f32x2){v[0], v[1]}; t1v[0] += (f32x2){v[2], v[3]};
+          t2v[0] += (f32x2){v[0], v[1]} * (f32x2){v[0], v[1]}; t2v[0] += (f32x2){v[2], v[3]} * (f32x2){v[2], v[3]};
+          t1v[1] += (f32x2){v[4], v[5]}; t1v[1] += (f32x2){v[6], v[7]};
+          t2v[1] += (f32x2){v[4], v[5]} * (f32x2){v[4], v[5]}; t2v[1] += (f32x2){v[6], v[7]} * (f32x2){v[6], v[7]};
         } else if (STM == 2) {
-          const float dy[8] = {bf_lo(w0x), bf_hi(w0x), bf_lo(w0y), bf_hi(w0y), bf_lo(w1x), bf_hi(w1x), bf_lo(w1y), bf_hi(w1y)};
-          const float xg[8] = {bf_lo(xx[mt][0].x), bf_hi(xx[mt][0].x), bf_lo(xx[mt][0].y), bf_hi(xx[mt][0].y),
-                               bf_lo(xx[mt][1].x), bf_hi(xx[mt][1].x), bf_lo(xx[mt][1].y), bf_hi(xx[mt][1].y)};
+          const float* dy = v;                             // (fp32 values, before the rounding of the store)
+          const float xg[8] = {bf_lo(u0), bf_hi(u0), bf_lo(u1), bf_hi(u1), bf_lo(u2), bf_hi(u2), bf_lo(u3), bf_hi(u3)};
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const float4 kk = ka[e >> 1];
             const float a = (e & 1) ? kk.z : kk.x, b = (e & 1) ? kk.w : kk.y;
             const float z = a * xg[e] + b;
-            const float dz = dy[e] * silu_grad_fast(z);
-            const float adz = a * dz;
+            const float adz = a * (dy[e] * silu_grad_fast(z));
             t1[e >> 2] += adz;
             t2[e >> 2] += adz * xg[e];
           }
@@ -369,50 +430,61 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
         *(uint4*)(yb + mt * rsy + coff + lane_y) = make_uint4(w0x, w0y, w1x, w1y);
         if (STM == 2) __builtin_amdgcn_sched_barrier(0);  // one pixel row at a time: 32 interleaved silu' chains would not fit the register file
       }
-      __builtin_amdgcn_sched_barrier(0);                 // keep the loads of the next (nt, k) group behind this one's stores
       if (STM == 1) {
-        s1[nt * 4 + 2 * k] = t1[0]; s2[nt * 4 + 2 * k] = t2[0];
-        s1[nt * 4 + 2 * k + 1] = t1[1]; s2[nt * 4 + 2 * k + 1] = t2[1];
+        ss[nt * 4 + 2 * k] = t1v[0][0] + t1v[0][1]; ss[8 + nt * 4 + 2 * k] = t2v[0][0] + t2v[0][1];
+        ss[nt * 4 + 2 * k + 1] = t1v[1][0] + t1v[1][1]; ss[8 + nt * 4 + 2 * k + 1] = t2v[1][0] + t2v[1][1];
       } else if (STM == 2) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-          s1[nt * 4 + 2 * k + q] = t1[q];
-          s2[nt * 4 + 2 * k + q] = (t2[q] - gm[q] * t1[q]) * gr[q];     // sum a*dz*xhat over this lane's values
+          ss[nt * 4 + 2 * k + q] = t1[q];
+          ss[8 + nt * 4 + 2 * k + q] = (t2[q] - gm[q] * t1[q]) * gr[q];     // sum a*dz*xhat over this lane's values
         }
       }
     }
   }
   if (STM) {
-    // pixels -> lane 0 of each half-wave; waves -> LDS; one fp64 atomic pair per channel quad
+    // 16 partial sums per lane, 32 pixel lanes per half-wave: butterfly reduce-scatter (8 + 4 + 2 + 1 exchanges, then one
+    // plain exchange) leaves value j = bits (4,3,2,1) of the lane index, summed over the half-wave, in every lane
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int st_ = 0; st_ < 4; ++st_) {
+      const int off = 16 >> st_, n = 8 >> st_;            // partner distance, values kept
+      const bool up = (pl & off) != 0;
 #pragma unroll
-      for (int o = 1; o < 32; o <<= 1) { s1[i] += __shfl_xor(s1[i], o, 64); s2[i] += __shfl_xor(s2[i], o, 64); }
-    float* sred = (float*)smem;                           // [wave][h][8][2]; the patch buffers are dead (last stage ended with a barrier)
-    if (pl == 0) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        sred[((wave * 2 + h) * 8 + i) * 2] = s1[i];
-        sred[((wave * 2 + h) * 8 + i) * 2 + 1] = s2[i];
+      for (int j = 0; j < n; ++j) {
+        const float send = up ? ss[j] : ss[j + n];
+        const float keep = up ? ss[j + n] : ss[j];
+        ss[j] = keep + __shfl_xor(send, off, 64);
       }
     }
+    ss[0] += __shfl_xor(ss[0], 1, 64);
+    float* sred = (float*)smem;                           // [wave][h][16]; the patch buffers are dead (barrier after the K loop)
+    if ((pl & 1) == 0) sred[(wave * 2 + h) * 16 + (pl >> 1)] = ss[0];
     __syncthreads();
-    if (tid < 32) {
-      // tid -> (wn', h', i): quad index i = nt * 4 + q of wave column wn'
-      const int wn2 = tid >> 4, h2 = (tid >> 3) & 1, i = tid & 7;
-      const float a = sred[(((0 * 2 + wn2) * 2 + h2) * 8 + i) * 2] + sred[(((1 * 2 + wn2) * 2 + h2) * 8 + i) * 2];
-      const float b = sred[(((0 * 2 + wn2) * 2 + h2) * 8 + i) * 2 + 1] + sred[(((1 * 2 + wn2) * 2 + h2) * 8 + i) * 2 + 1];
+    if (tid < 64) {
+      // tid -> (wn', h', j): j < 8: sum 1 of quad j = nt * 4 + q, j >= 8: sum 2
+      const int wn2 = tid >> 5, h2 = (tid >> 4) & 1, j = tid & 15;
+      const float a = sred[((0 * 2 + wn2) * 2 + h2) * 16 + j] + sred[((1 * 2 + wn2) * 2 + h2) * 16 + j];
+      const int i = j & 7;
       const int ch = nb * C3_BN + wn2 * 64 + (i >> 2) * 32 + (i & 3) * 8 + 4 * h2;
-      double* dst = p.st_sums + ((long)img * 32 + ch / cpg) * 2;
-      atomicAdd(dst, (double)a);
-      atomicAdd(dst + 1, (double)b);
+#if C3_ABL_NOATOM
+      if (a == 12345.678f) p.st_sums[0] = a;
+#else
+      atomicAdd(p.st_sums + ((long)img * 32 + ch / cpg) * 2 + (j >> 3), (double)a);
+#endif
     }
   }
+  C3_STAMP(3);
+#if C3_TIMING
+  if (p.dbg && threadIdx.x == 0) {
+    p.dbg[(long)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // HW_REG_XCC_ID
+    p.dbg[(long)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID (wave / simd / cu / sh / se)
+  }
+#endif
 }
 
-template <int TF, int STM>
+template <int TF, int STM, bool RES>
 int launch3(const Conv3Params& p, hipStream_t st) {
-  auto kern = conv3_kernel<TF, STM>;
+  auto kern = conv3_kernel<TF, STM, RES>;
   static std::atomic<unsigned long long> granted{0};     // dynamic-LDS cap raised once per (instantiation, device)
   int dev = 0;
   KDIP_HIP_CHECK(hipGetDevice(&dev));
@@ -428,6 +500,14 @@ int launch3(const Conv3Params& p, hipStream_t st) {
 
 }  // namespace
 
+int conv3_debug_timing(void* buf) {
+  if (!C3_TIMING) return set_error(KDIP_ERR_UNSUPPORTED, "conv3 timing: library not built with -DC3_TIMING=1");
+  g_c3_dbg = (unsigned long long*)buf;
+  return KDIP_OK;
+}
+
+int conv3_tf_max_cin(int tf) { return c3_max_cin(tf); }
+
 bool conv3_eligible(DType dt, int ntaps, int H, int W, int Cin_pad, int Cout, long ldx, long ldy) {
   return dt == DT_BF16 && ntaps == 9 && H % C3_TH == 0 && W % C3_TW == 0 && Cin_pad % 32 == 0 && Cout % C3_BN == 0 &&
          ldx % 8 == 0 && ldy % 8 == 0;
@@ -437,7 +517,7 @@ int conv3_forward(hipStream_t st, const void* x, long ldx, int B, int H, int W, 
                   void* y, long ldy, const void* res, long ldr, const Conv3Fuse* fu, int cin_real) {
   KDIP_REQUIRE(conv3_eligible(DT_BF16, 9, H, W, Cin, Cout, ldx, ldy), "conv3: shape not eligible (H=%d W=%d Cin=%d Cout=%d)", H, W, Cin, Cout);
   KDIP_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)wp % 16) == 0 && ((uintptr_t)y % 16) == 0, "conv3: pointers must be 16-byte aligned");
-  KDIP_REQUIRE(!res || (ldr % 4 == 0 && (uintptr_t)res % 8 == 0), "conv3: residual must be 8-byte aligned");
+  KDIP_REQUIRE(!res || (ldr % 8 == 0 && (uintptr_t)res % 16 == 0), "conv3: residual must be 16-byte aligned");
   Conv3Params p{};
   p.x = (const bf16_t*)x; p.ldx = ldx; p.wp = (const uint4*)wp; p.bias = bias; p.res = (const bf16_t*)res; p.ldr = ldr;
   p.y = (bf16_t*)y; p.ldy = ldy; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
@@ -450,6 +530,7 @@ int conv3_forward(hipStream_t st, const void* x, long ldx, int B, int H, int W, 
     p.st_coef = fu->st_coef; p.st_mr = fu->st_mr;
   }
   KDIP_REQUIRE(!(p.in_ups || p.res_ups) || (H % 2 == 0 && W % 2 == 0), "conv3: fused x2 upsample needs even H, W");
+p.dbg = C3_TIMING ? g_c3_dbg : nullptr;
   KDIP_REQUIRE(tf >= 0 && tf <= 2 && stm >= 0 && stm <= 2, "conv3: bad fusion modes");
   // every GroupNorm in front of / behind a 3x3 conv of the UNet is followed by SiLU: the activation is compiled in (a
   // run-time switch doubled the epilogue's register footprint: 170 spilled VGPRs)
@@ -459,18 +540,26 @@ int conv3_forward(hipStream_t st, const void* x, long ldx, int B, int H, int W, 
   KDIP_REQUIRE(Cin <= c3_max_cin(tf), "conv3: too many input channels (%d) for the staging-transform table", Cin);
   KDIP_REQUIRE((long)H * W * ldx * 2 < (1L << 31), "conv3: image too large for 32-bit staging offsets");
   KDIP_REQUIRE(stm == 0 || ((Cout >> 5) % 4 == 0 && p.st_sums), "conv3: fused statistics need Cout / 32 to be a multiple of 4");
-  KDIP_REQUIRE(stm != 2 || (p.st_x && p.st_ldx % 4 == 0 && (uintptr_t)p.st_x % 8 == 0 && (uintptr_t)p.st_coef % 16 == 0 && (uintptr_t)p.st_mr % 8 == 0),
+  KDIP_REQUIRE(stm != 2 || (p.st_x && p.st_ldx % 8 == 0 && (uintptr_t)p.st_x % 16 == 0 && (uintptr_t)p.st_coef % 16 == 0 && (uintptr_t)p.st_mr % 8 == 0),
                "conv3: backward statistics need the GroupNorm input / coefficients (aligned)");
   if (g_prof_on) {
     const double px = (double)B * H * W;
     const int cr = cin_real > 0 ? cin_real : Cin;
     prof_begin(st, PC_CONV3_128x128, 2.0 * px * cr * Cout * 9, px * (cr + Cout) * 2.0 + 9.0 * cr * Cout * 2.0, tf ? (tf == 1 ? "conv3_gnf" : "conv3_gnb") : "conv3", B, H, cr, Cout);
   }
+  // instantiated combinations: forward convs (tf 0 / 1, statistics 0 / 1, with / without residual) and dgrad convs
+  // (tf 0 / 2, statistics 0 / 2, never a residual)
+  KDIP_REQUIRE(!(res && (tf == 2 || stm == 2)), "conv3: residual together with GroupNorm-backward fusion is not instantiated");
+  KDIP_REQUIRE(!(tf == 1 && stm == 2) && !(tf == 2 && stm == 1), "conv3: fusion mode combination is not instantiated");
   int rc;
-#define C3_GO(T, S) rc = launch3<T, S>(p, st)
-  if (tf == 0) { if (stm == 0) C3_GO(0, 0); else if (stm == 1) C3_GO(0, 1); else C3_GO(0, 2); }
-  else if (tf == 1) { if (stm == 0) C3_GO(1, 0); else if (stm == 1) C3_GO(1, 1); else C3_GO(1, 2); }
-  else { if (stm == 0) C3_GO(2, 0); else if (stm == 1) C3_GO(2, 1); else C3_GO(2, 2); }
+#define C3_GO(T, S, R) rc = launch3<T, S, R>(p, st)
+  if (tf == 0 && stm == 0) { if (res) C3_GO(0, 0, true); else C3_GO(0, 0, false); }
+  else if (tf == 0 && stm == 1) { if (res) C3_GO(0, 1, true); else C3_GO(0, 1, false); }
+  else if (tf == 1 && stm == 0) { if (res) C3_GO(1, 0, true); else C3_GO(1, 0, false); }
+  else if (tf == 1 && stm == 1) { if (res) C3_GO(1, 1, true); else C3_GO(1, 1, false); }
+  else if (tf == 0 && stm == 2) C3_GO(0, 2, false);
+  else if (tf == 2 && stm == 0) C3_GO(2, 0, false);
+  else C3_GO(2, 2, false);
 #undef C3_GO
   prof_end(st);
   if (rc) return rc;

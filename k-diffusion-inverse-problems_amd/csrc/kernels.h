@@ -43,6 +43,8 @@ struct Conv3Fuse {
   const void* st_x = nullptr; long st_ldx = 0;
   const float* st_coef = nullptr; const float* st_mr = nullptr;
 };
+int conv3_debug_timing(void* buf);   // -DC3_TIMING=1 builds: [grid][8] uint64 per-block phase stamps of every later conv3 launch
+int conv3_tf_max_cin(int tf);          // most input channels the staging-transform table of mode tf holds
 bool conv3_eligible(DType dt, int ntaps, int H, int W, int Cin_pad, int Cout, long ldx, long ldy);
 int conv3_forward(hipStream_t st, const void* x, long ldx, int B, int H, int W, int Cin, const void* wp, const float* bias, int Cout,
                   void* y, long ldy, const void* res, long ldr, const Conv3Fuse* fu, int cin_real = 0);
@@ -75,6 +77,8 @@ int gn_bwd_stats(hipStream_t st, DType dt, const void* x, long ldx, const void* 
 int gn_bwd_apply(hipStream_t st, DType dt, const void* x, long ldx, const void* dy, long lddy, const float* coef,
                  const float* mr, const double* sums, int B, long HW, int C, int silu, const void* addend, long lda,
                  void* dx, long lddx, const void* addend2 = nullptr, long lda2 = 0, int half_lgW = -1);
+// (a, b, k0, k1) per (image, channel) for a dgrad conv that applies this GroupNorm backward while staging (Conv3Fuse::tf 2)
+int gn_bwd_coef(hipStream_t st, const float* coef, const float* mr, const double* sums, int B, long HW, int C, float* out);
 // half_lgW >= 0 (W = 1 << half_lgW): dy / addend are HALF-resolution tensors standing for 0.25 * nearest-upsample (the adjoint
 // of the 2x2 average pool of a downsampling ResBlock), read in place instead of being materialised at full resolution.
 // GN apply (+SiLU) fused with the 2x2 average pool of both the activated tensor (yp) and the raw input (xp)

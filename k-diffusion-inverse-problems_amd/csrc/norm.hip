@@ -425,6 +425,25 @@ int gn_bwd_apply(hipStream_t st, DType dt, const void* x, long ldx, const void* 
   return KDIP_OK;
 }
 
+// Per-channel constants of the GroupNorm backward  dx = a*dz - (k0 + k1*x)  for the dgrad conv that applies it while staging
+// its input patch (conv3.hip, tf 2): out[B][C][4] = (a, b, k0, k1), k1 = rstd*T2/N, k0 = T1/N - mean*k1 (as gn_bwd_apply_kernel).
+__global__ void gn_bwd_coef_kernel(const float* __restrict__ coef, const float* __restrict__ mr, const double* __restrict__ sums,
+                                   int B, long HW, int C, float4* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i % C, cpg = C / 32, g = c / cpg;
+  const float invN = 1.f / ((float)HW * (float)cpg);
+  const float mean = mr[((long)b * 32 + g) * 2], rstd = mr[((long)b * 32 + g) * 2 + 1];
+  const float t1 = (float)sums[((long)b * 32 + g) * 2] * invN, t2 = (float)sums[((long)b * 32 + g) * 2 + 1] * invN;
+  const float k1 = rstd * t2, k0 = t1 - mean * k1;
+  out[i] = make_float4(coef[(long)i * 2], coef[(long)i * 2 + 1], k0, k1);
+}
+int gn_bwd_coef(hipStream_t st, const float* coef, const float* mr, const double* sums, int B, long HW, int C, float* out) {
+  hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(cdiv((long)B * C, 256)), dim3(256), 0, st, coef, mr, sums, B, HW, C, (float4*)out);
+  KDIP_LAUNCH_CHECK();
+  return KDIP_OK;
+}
+
 // ------------------------------------------------------------- small feature maps ----
 // HW <= 256 (the 8x8 and 16x16 levels): the whole (image, group) slab is a few KB, so the
 // stats / coef / apply chain (3 launches forward, 2 backward, each launch-latency bound at

@@ -267,13 +267,14 @@ struct Ctx {
 double* new_sums(Ctx& c, int B) { return (double*)c.u->zeros.alloc(sizeof(double) * B * 64); }
 
 // pool_W > 0: y / pool_x receive the 2x2-average-pooled activated / raw tensors instead (downsampling ResBlock)
+// y == nullptr: statistics + coefficients only (the apply is fused into the consuming conv's input staging, conv3.hip)
 int gn_forward(Ctx& c, const void* x, long ldx, int B, long HW, const GnW& g, const float* film, int silu, void* y,
                long ldy, float** coef_out, float** mr_out, long film_ld = 0, int pool_W = 0, void* pool_x = nullptr) {
   bool dry = c.dry;
   float* coef = (float*)c.u->persist.alloc(sizeof(float) * B * g.C * 2);
   float* mr = (float*)c.u->persist.alloc(sizeof(float) * B * 64);
   *coef_out = coef; *mr_out = mr;
-  if (gn_small_eligible(c.dt, HW, g.C)) {
+  if (y && gn_small_eligible(c.dt, HW, g.C)) {
     RUN(gn_fwd_small(c.st, c.dt, x, ldx, B, HW, g.C, g.gamma, g.beta, film, film_ld, 1e-5f, silu, y, ldy, coef, mr));
     return KDIP_OK;
   }
@@ -297,6 +298,7 @@ int gn_forward(Ctx& c, const void* x, long ldx, int B, long HW, const GnW& g, co
     RUN(gn_stats(c.st, c.dt, x, ldx, B, HW, g.C, stats, 1));
   }
   RUN(gn_coef(c.st, stats, g.gamma, g.beta, film, B, HW, g.C, 1e-5f, coef, mr, film_ld));
+  if (!y) return KDIP_OK;
   if (pool_W > 0) RUN(gn_apply_pool2(c.st, c.dt, x, ldx, coef, B, (int)(HW / pool_W), pool_W, g.C, silu, y, ldy, pool_x, g.C));
   else RUN(gn_apply(c.st, c.dt, x, ldx, coef, B, HW, g.C, silu, y, ldy));
   *coef_out = coef; *mr_out = mr;
@@ -320,13 +322,48 @@ int gn_backward(Ctx& c, const void* x, long ldx, const void* dy, long lddy, cons
   return KDIP_OK;
 }
 
+#ifndef KDIP_CONV3
+#define KDIP_CONV3 1        // 0: first-generation kernels everywhere (A/B builds)
+#endif
+// true iff this conv runs on the second-generation kernel (bf16, large maps) and can therefore take a fused GroupNorm transform
+#ifndef KDIP_CONV3_MIN_BLOCKS
+#define KDIP_CONV3_MIN_BLOCKS 192     // its 256-pixel x 128-channel tiles must at least roughly fill the chip (the 32x32 level does not at batch 8)
+#endif
+// tf: staging transform the caller wants fused (0 none, 1 GroupNorm forward, 2 GroupNorm backward)
+bool use_conv3(Ctx& c, const ConvW& w, int B, int H, int W, long ldx, long ldy, bool dgrad, int out_f32, int tf = 0) {
+  if (!KDIP_CONV3 || out_f32) return false;
+  const int cin = dgrad ? w.cin_pad_b : w.cin_pad, cout = dgrad ? w.cin : w.cout;
+  if (!conv3_eligible(c.dt, w.ntaps, H, W, cin, cout, ldx, ldy)) return false;
+  if ((long)B * (H / 8) * (W / 32) * (cout / 128) < KDIP_CONV3_MIN_BLOCKS) return false;
+  if (tf && cin > conv3_tf_max_cin(tf)) return false;
+  // the GroupNorm-backward transform (two tensors, silu') is re-done by every 128-channel output block: fuse it only when there is one
+  if (tf == 2 && cout != 128) return false;
+  return true;
+}
+
 // in_ups / res_ups: x / res are half-resolution tensors read through a fused nearest x2 upsample (H, W = output size)
+// tf_coef: the input is a GroupNorm INPUT and (a, b) [B][cin][2] are its coefficients: silu(a*x + b) is applied while the
+// patch is staged (only when use_conv3())
 int conv_f(Ctx& c, const ConvW& w, const void* x, long ldx, int B, int H, int W, void* y, long ldy, const void* res,
-           long ldr, int out_f32, bool fuse_out_stats = false, int in_ups = 0, int res_ups = 0) {
+           long ldr, int out_f32, bool fuse_out_stats = false, int in_ups = 0, int res_ups = 0, const float* tf_coef = nullptr) {
   bool dry = c.dry;
+  const bool stats_ok = fuse_out_stats && !out_f32 && conv_stats_eligible(H, W, w.cout) && !gn_small_eligible(c.dt, (long)H * W, w.cout);
+  if (use_conv3(c, w, B, H, W, ldx, ldy, false, out_f32, tf_coef ? 1 : 0)) {
+    Conv3Fuse fu;
+    fu.in_ups = in_ups; fu.res_ups = res_ups;
+    if (tf_coef) { fu.tf = 1; fu.tf_silu = 1; fu.tf_coef = tf_coef; }
+    if (stats_ok) {
+      fu.st_mode = 1;
+      fu.st_sums = new_sums(c, B);
+      c.u->fused_stats[std::make_pair((const void*)y, w.cout)] = fu.st_sums;
+    }
+    RUN(conv3_forward(c.st, x, ldx, B, H, W, w.cin_pad, w.wf, w.bias, w.cout, y, ldy, res, ldr, &fu, w.cin));
+    return KDIP_OK;
+  }
+  if (tf_coef) return set_error(KDIP_ERR_STATE, "internal: fused GroupNorm staging requested for a conv the second-generation kernel cannot run");
   ConvStats stt;
   stt.in_ups = in_ups; stt.res_ups = res_ups;
-  if (fuse_out_stats && !out_f32 && conv_stats_eligible(H, W, w.cout) && !gn_small_eligible(c.dt, (long)H * W, w.cout)) {
+  if (stats_ok) {
     stt.mode = 1;
     stt.sums = new_sums(c, B);
     c.u->fused_stats[std::make_pair((const void*)y, w.cout)] = stt.sums;
@@ -338,13 +375,29 @@ int conv_f(Ctx& c, const ConvW& w, const void* x, long ldx, int B, int H, int W,
 // input-gradient: x here is dL/d(out) with >= cin_pad_b channels available (zero padded when cout % 32 != 0)
 // gn_*: when given, the GroupNorm-backward sums of the produced gradient (w.r.t. the GN whose input is
 // gn_x) are accumulated in the epilogue; *sums_out receives the buffer (or nullptr if not eligible).
+// tf2_*: g is dL/d(GroupNorm output) of the GroupNorm whose input is tf2_x2 and tf2_coef = (a, b, k0, k1) [B][cout][4]: the
+// GroupNorm backward is applied while the patch is staged (only when use_conv3())
 int conv_b(Ctx& c, const ConvW& w, const void* g, long ldg, int B, int H, int W, void* y, long ldy, const void* res,
            long ldr, int out_f32, const void* gn_x = nullptr, long gn_ldx = 0, const float* gn_coef = nullptr,
-           const float* gn_mr = nullptr, int gn_silu = 0, double** sums_out = nullptr) {
+           const float* gn_mr = nullptr, int gn_silu = 0, double** sums_out = nullptr, const float* tf2_coef = nullptr,
+           const void* tf2_x2 = nullptr) {
   bool dry = c.dry;
-  ConvStats stt;
   if (sums_out) *sums_out = nullptr;
-  if (gn_x && sums_out && !out_f32 && ldy == w.cin && conv_stats_eligible(H, W, w.cin) && !gn_small_eligible(c.dt, (long)H * W, w.cin)) {
+  const bool stats_ok = gn_x && sums_out && !out_f32 && ldy == w.cin && conv_stats_eligible(H, W, w.cin) && !gn_small_eligible(c.dt, (long)H * W, w.cin);
+  if (use_conv3(c, w, B, H, W, ldg, ldy, true, out_f32, tf2_coef ? 2 : 0) && !res && (!stats_ok || gn_silu)) {
+    Conv3Fuse fu;
+    if (tf2_coef) { fu.tf = 2; fu.tf_silu = 1; fu.tf_coef = tf2_coef; fu.x2 = tf2_x2; fu.ldx2 = ldg; }
+    if (stats_ok) {
+      fu.st_mode = 2; fu.st_silu = 1; fu.st_x = gn_x; fu.st_ldx = gn_ldx; fu.st_coef = gn_coef; fu.st_mr = gn_mr;
+      fu.st_sums = new_sums(c, B);
+      *sums_out = fu.st_sums;
+    }
+    RUN(conv3_forward(c.st, g, ldg, B, H, W, w.cin_pad_b, w.wb, nullptr, w.cin, y, ldy, nullptr, 0, &fu, w.cout));
+    return KDIP_OK;
+  }
+  if (tf2_coef) return set_error(KDIP_ERR_STATE, "internal: fused GroupNorm-backward staging requested for a conv the second-generation kernel cannot run");
+  ConvStats stt;
+  if (stats_ok) {
     stt.mode = 2; stt.silu = gn_silu; stt.x = gn_x; stt.ldx = gn_ldx; stt.coef = gn_coef; stt.mr = gn_mr;
     stt.sums = new_sums(c, B);
     *sums_out = stt.sums;
@@ -399,12 +452,20 @@ static int res_forward(Ctx& c, Layer& L, const void* x, long ldx, int B, int& H,
   L.sv.x = x; L.sv.ldx = ldx; L.sv.B = B; L.sv.H = H; L.sv.W = W;
   const long HW = (long)H * W;
   const bool fused_pool = L.mode == 1 && !gn_small_eligible(c.dt, HW, L.cin);   // GN + SiLU + both 2x2 pools in one pass over x
-  void* h1 = fused_pool ? nullptr : u->scratch.alloc(es * B * HW * L.cin);
+  int Ho = H, Wo = W, ups = 0;
+  if (L.mode == 1) { Ho = H / 2; Wo = W / 2; }
+  if (L.mode == 2) { Ho = H * 2; Wo = W * 2; ups = 1; }
+  const long HWo = (long)Ho * Wo;
+  void* o = dst ? dst : u->persist.alloc(es * B * HWo * L.cout);
+  const long ldo = dst ? ldd : L.cout;
+  // GroupNorm + SiLU applied inside the consuming conv's input staging (second-generation kernel): the activated tensors
+  // h1 / h3 are never written.  Not for downsampling blocks (the pool sits between SiLU and conv1) and small maps.
+  const bool f1 = L.mode != 1 && use_conv3(c, L.c1, B, Ho, Wo, ldx, L.cout, false, 0, 1) && (L.mode != 2 || !gn_small_eligible(c.dt, HW, L.cin));
+  const bool f2 = use_conv3(c, L.c2, B, Ho, Wo, L.cout, ldo, false, 0, 1);
+  void* h1 = (fused_pool || f1) ? nullptr : u->scratch.alloc(es * B * HW * L.cin);
   if (!fused_pool) CK(gn_forward(c, x, ldx, B, HW, L.n1, nullptr, 1, h1, L.cin, &L.sv.coef1, &L.sv.mr1));
   const void* cin_ptr = h1; const void* xs = x; long ldxs = ldx;
-  int Ho = H, Wo = W, ups = 0;
   if (L.mode == 1) {
-    Ho = H / 2; Wo = W / 2;
     void* h1p = u->scratch.alloc(es * B * Ho * Wo * L.cin);
     void* xp = u->scratch.alloc(es * B * Ho * Wo * L.cin);
     if (fused_pool) {
@@ -414,18 +475,15 @@ static int res_forward(Ctx& c, Layer& L, const void* x, long ldx, int B, int& H,
       RUN(avgpool2(c.st, c.dt, x, ldx, B, H, W, L.cin, xp, L.cin, 0.25f));
     }
     cin_ptr = h1p; xs = xp; ldxs = L.cin;
-  } else if (L.mode == 2) {
-    // Upsample(use_conv=False) of both branches (unet.py:232-235) is folded into the consumers' reads: conv1 and the skip
-    // path read the half-resolution tensors at (y >> 1, x >> 1); no 4x-sized copies are written or re-read
-    Ho = H * 2; Wo = W * 2;
-    ups = 1;
   }
-  const long HWo = (long)Ho * Wo;
+  // (mode 2: Upsample(use_conv=False) of both branches (unet.py:232-235) is folded into the consumers' reads: conv1 and the
+  // skip path read the half-resolution tensors at (y >> 1, x >> 1); no 4x-sized copies are written or re-read)
   void* h2 = u->persist.alloc(es * B * HWo * L.cout);
   L.sv.h2 = h2;
-  CK(conv_f(c, L.c1, cin_ptr, L.cin, B, Ho, Wo, h2, L.cout, nullptr, 0, 0, true, ups, 0));
+  if (f1) CK(conv_f(c, L.c1, x, ldx, B, Ho, Wo, h2, L.cout, nullptr, 0, 0, true, ups, 0, L.sv.coef1));
+  else CK(conv_f(c, L.c1, cin_ptr, L.cin, B, Ho, Wo, h2, L.cout, nullptr, 0, 0, true, ups, 0));
   const float* film = film_all + L.emb_off;          // row b at film + b * emb_total
-  void* h3 = u->scratch.alloc(es * B * HWo * L.cout);
+  void* h3 = f2 ? nullptr : u->scratch.alloc(es * B * HWo * L.cout);
   CK(gn_forward(c, h2, L.cout, B, HWo, L.n2, film, 1, h3, L.cout, &L.sv.coef2, &L.sv.mr2, u->emb_total));
   const void* S = xs; long ldS = ldxs;
   if (L.has_skip) {
@@ -433,8 +491,9 @@ static int res_forward(Ctx& c, Layer& L, const void* x, long ldx, int B, int& H,
     CK(conv_f(c, L.skip, xs, ldxs, B, Ho, Wo, sk, L.cout, nullptr, 0, 0, false, ups, 0));
     S = sk; ldS = L.cout;
   }
-  void* o = dst ? dst : u->persist.alloc(es * B * HWo * L.cout);
-  CK(conv_f(c, L.c2, h3, L.cout, B, Ho, Wo, o, dst ? ldd : L.cout, S, ldS, 0, true, 0, (ups && !L.has_skip) ? 1 : 0));
+  const int rups = (ups && !L.has_skip) ? 1 : 0;
+  if (f2) CK(conv_f(c, L.c2, h2, L.cout, B, Ho, Wo, o, ldo, S, ldS, 0, true, 0, rups, L.sv.coef2));
+  else CK(conv_f(c, L.c2, h3, L.cout, B, Ho, Wo, o, ldo, S, ldS, 0, true, 0, rups));
   *outp = o; H = Ho; W = Wo;
   return KDIP_OK;
 }
@@ -599,15 +658,25 @@ static int res_backward(Ctx& c, Layer& L, const void* G, long ldG, void** gxp, c
   void* g3 = u->scratch.alloc(es * B * HWo * L.cout);
   double* sums2 = nullptr;     // GN2-backward sums accumulated by the dgrad epilogue when the shape allows
   CK(conv_b(c, L.c2, G, ldG, B, Ho, Wo, g3, L.cout, nullptr, 0, 0, L.sv.h2, L.cout, L.sv.coef2, L.sv.mr2, 1, &sums2));
-  void* gh2 = u->scratch.alloc(es * B * HWo * L.cout);
-  CK(gn_backward(c, L.sv.h2, L.cout, g3, L.cout, L.sv.coef2, L.sv.mr2, B, HWo, L.cout, 1, nullptr, 0, gh2, L.cout, sums2));
-  // conv1 dgrad -> grad wrt (resampled) h1
+  // conv1 dgrad -> grad wrt (resampled) h1.  Second-generation kernel + fused sums: the GN2 backward apply
+  // (gh2 = a*dz - (k0 + k1*h2)) happens inside the dgrad conv's input staging; gh2 is never written.
   void* g1p = u->scratch.alloc(es * B * HWo * L.cin);
   double* sums1 = nullptr;
+  const bool fb = sums2 && use_conv3(c, L.c1, B, Ho, Wo, L.cout, L.cin, true, 0, 2);
+  const void* gh2 = nullptr;
+  float* tf2 = nullptr;
+  if (fb) {
+    tf2 = (float*)u->scratch.alloc(sizeof(float) * B * L.cout * 4);
+    RUN(gn_bwd_coef(c.st, L.sv.coef2, L.sv.mr2, sums2, B, HWo, L.cout, tf2));
+  } else {
+    void* t = u->scratch.alloc(es * B * HWo * L.cout);
+    CK(gn_backward(c, L.sv.h2, L.cout, g3, L.cout, L.sv.coef2, L.sv.mr2, B, HWo, L.cout, 1, nullptr, 0, t, L.cout, sums2));
+    gh2 = t;
+  }
   if (L.mode == 0)
-    CK(conv_b(c, L.c1, gh2, L.cout, B, Ho, Wo, g1p, L.cin, nullptr, 0, 0, L.sv.x, L.sv.ldx, L.sv.coef1, L.sv.mr1, 1, &sums1));
+    CK(conv_b(c, L.c1, fb ? g3 : gh2, L.cout, B, Ho, Wo, g1p, L.cin, nullptr, 0, 0, L.sv.x, L.sv.ldx, L.sv.coef1, L.sv.mr1, 1, &sums1, tf2, fb ? L.sv.h2 : nullptr));
   else
-    CK(conv_b(c, L.c1, gh2, L.cout, B, Ho, Wo, g1p, L.cin, nullptr, 0, 0));
+    CK(conv_b(c, L.c1, fb ? g3 : gh2, L.cout, B, Ho, Wo, g1p, L.cin, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, 0, nullptr, tf2, fb ? L.sv.h2 : nullptr));
   // skip path: grad wrt (resampled) x
   const void* gS = G; long ldgS = ldG;
   if (L.has_skip) {

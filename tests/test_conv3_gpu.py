@@ -86,9 +86,12 @@ def test_conv3_fused_groupnorm_silu_staging_and_forward_stats():
     A = bf(F.silu(a_ * bf(x) + b_))
     ref = F.conv2d(A, bf(w), b, padding=1)
     assert rel_err(y, ref) < 1.5e-2
-    yr = y.double().view(B, 32, -1)                   # statistics of the values the kernel stored
-    s_ref = torch.stack([yr.sum(-1), (yr * yr).sum(-1)], dim=-1)
-    assert float((sums - s_ref).abs().max() / s_ref.abs().max()) < 1e-5
+    yr = y.double().view(B, 32, -1)                   # the kernel sums its fp32 values before the bf16 rounding of the store:
+    s_ref = torch.stack([yr.sum(-1), (yr * yr).sum(-1)], dim=-1)      # vs the stored values the sums differ by rounding noise only
+    assert float((sums - s_ref).abs().max() / s_ref.abs().max()) < 1e-3
+    yf = ref.double().view(B, 32, -1)                 # and agree with the fp32 reference conv more closely
+    s_f = torch.stack([yf.sum(-1), (yf * yf).sum(-1)], dim=-1)
+    assert float((sums - s_f).abs().max() / s_f.abs().max()) < 2e-4
 
 
 def test_conv3_fused_upsample_reads():
