@@ -42,6 +42,10 @@ constexpr int C3_LDS = 2 * C3_ABUF + C3_NSLOT * C3_BSLOT; // 78976 B (+ 64 B dum
 // The per-channel coefficients of the staging transform ride in the 16-byte PADS of the patch pixels (never touched by the
 // staging writes or the fragment reads): table slot j = pad of pixel j % 336 of patch buffer j / 336 -> 672 slots.
 // TF 1: slot = 2 channels x (a, b); TF 2: slot = 1 channel x (a, b, k0, k1).
+constexpr int C3_LDS_TOTAL = C3_LDS + 64 + 512;           // + dummy staging slot + statistics exchange [4 waves][2][16] floats
+#ifndef C3_BLOCKS_PER_CU
+#define C3_BLOCKS_PER_CU 2
+#endif
 constexpr int C3_TABPIX = 336, C3_TABSLOTS = 2 * C3_TABPIX;
 constexpr int c3_max_cin(int tf) { return tf == 1 ? 2 * C3_TABSLOTS : (tf == 2 ? C3_TABSLOTS : (1 << 20)); }
 __device__ __forceinline__ int c3_tab_off(int slot) { return (slot / C3_TABPIX) * C3_ABUF + (slot % C3_TABPIX) * C3_PIXB + 64; }
@@ -56,6 +60,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #endif
 #ifndef C3_ABL_NOEPI
 #define C3_ABL_NOEPI 0
+#endif
+#ifndef C3_SCHED_GROUPS
+#define C3_SCHED_GROUPS 1      // pin the fragment-read / MFMA issue order of the plain (TF 0) kernels
+#endif
+#ifndef C3_AUX_PREFETCH
+#define C3_AUX_PREFETCH 0      // measured: touching the epilogue's lines from the K loop does not pay (+5 %: the epilogue is not latency bound)
 #endif
 #ifndef C3_TIMING
 #define C3_TIMING 0            // diagnostic build: per-block phase stamps (100 MHz) into the buffer set by conv3_debug_timing
@@ -99,60 +109,85 @@ __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w <<
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
 // TF: staging transform (0 none, 1 GroupNorm forward apply, 2 GroupNorm backward apply); STM: statistics mode of the output
+//
+// PERSISTENT blocks: (2 per CU) x (CUs) workgroups walk the tile list; XCD k (= blockIdx % 8) owns a contiguous tile range
+// (neighbouring halos and all n-blocks of an m-tile share one L2).  The staging pipeline runs ACROSS tile boundaries: during a
+// tile's last chunk the vectors being staged and the weight DMAs of the last two stages already belong to the block's next
+// tile, so a tile starts without the load -> transform -> LDS -> barrier prologue (3.6 - 10 us of a 30 - 45 us tile).
 template <int TF, int STM, bool RES>
 __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  // ---- XCD-aware bijective block -> tile map (all n-blocks of an m-tile and neighbouring tiles share one XCD's L2)
   const int ntiles = p.mtiles * p.nblkN;
-  const int xq = ntiles >> 3, xr = ntiles & 7, xcd = blockIdx.x & 7, xj = blockIdx.x >> 3;
-  const int bid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xj;
-  if (xj >= xq + (xcd < xr ? 1 : 0)) return;
+  const int xq = ntiles >> 3, xr = ntiles & 7, xcd = blockIdx.x & 7;
+  const int xstart = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq, xend = xstart + xq + (xcd < xr ? 1 : 0);
+  const int nper = gridDim.x >> 3;                       // blocks per XCD share
+  int cur = xstart + (blockIdx.x >> 3);
+  if (cur >= xend) return;
   C3_STAMP(0);
-  const int mtile = bid / p.nblkN, nb = bid - mtile * p.nblkN;
   const int tpi = p.tilesX * p.tilesY;
-  const int img = mtile / tpi, trem = mtile - img * tpi;
-  const int ty0 = trem / p.tilesX;
-  const int y0 = ty0 * C3_TH, x0 = (trem - ty0 * p.tilesX) * C3_TW;
-
-  // ---- staging descriptors: vector v = tid + 256 i -> (halo pixel v >> 2, 16-byte channel group v & 3 = tid & 3).
-  // Byte offsets are relative to the image (32 bits); padding / out-of-patch lanes read offset 0 and are zeroed when written,
-  // so every wave issues exactly the same number of loads (the K loop counts its outstanding loads by hand, see below).
   const int Hs = p.in_ups ? p.H >> 1 : p.H, Ws = p.in_ups ? p.W >> 1 : p.W;
-  const bf16_t* const ximg = p.x + (long)img * Hs * Ws * p.ldx;
-  const bf16_t* const x2img = TF == 2 ? p.x2 + (long)img * Hs * Ws * p.ldx : p.x;       // same geometry as x (checked on the host)
+  const int nchunks = p.Cin >> 5;
+  const long kStride = (long)p.ntilesN * 64, tapStride = (long)(p.Cin >> 4) * kStride;     // packed weights, in 16-byte units
+
+  // ---- staging descriptors of the tile whose chunks are being STAGED (the current tile, or -- during its last chunk -- the
+  // next one): vector v = tid + 256 i -> (halo pixel v >> 2, 16-byte channel group tid & 3).  Byte offsets are relative to the
+  // image (32 bits); padding / out-of-patch lanes read offset 0 and are zeroed when written, so every wave issues exactly the
+  // same number of loads (the K loop counts its outstanding loads by hand, see below).
   unsigned goff[C3_MAXV];
   unsigned zmask = 0;                  // bit i: vector i is zero fill (conv padding); bit 8 + i: vector i is outside the patch
+  const bf16_t* ximg = p.x;
+  const bf16_t* x2img = p.x;
+  int tab_img = -1;                    // image whose transform coefficients sit in the LDS table
+  auto set_staging = [&](int bid) {
+    const int mtile = bid / p.nblkN;
+    const int im = mtile / tpi, trem = mtile - im * tpi;
+    const int ty = trem / p.tilesX;
+    const int yy = ty * C3_TH, xx = (trem - ty * p.tilesX) * C3_TW;
+    ximg = p.x + (long)im * Hs * Ws * p.ldx;
+    if (TF == 2) x2img = p.x2 + (long)im * Hs * Ws * p.ldx;          // same geometry as x (checked on the host)
+    zmask = 0;
 #pragma unroll
-  for (int i = 0; i < C3_MAXV; ++i) {
-    const int v = tid + i * 256, pix = v >> 2;
-    const int hy = pix / C3_PW, hx = pix - hy * C3_PW;
-    const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-    goff[i] = (unsigned)((tid & 3) * 16);
-    if (pix >= C3_NPIX) zmask |= 0x101u << i;
-    else if (gy < 0 || gy >= p.H || gx < 0 || gx >= p.W) zmask |= 1u << i;
-    else {
-      const int spix = p.in_ups ? (gy >> 1) * Ws + (gx >> 1) : gy * Ws + gx;
-      goff[i] = (unsigned)((spix * (int)p.ldx + (tid & 3) * 8) * 2);
+    for (int i = 0; i < C3_MAXV; ++i) {
+      const int v = tid + i * 256, pix = v >> 2;
+      const int hy = pix / C3_PW, hx = pix - hy * C3_PW;
+      const int gy = yy + hy - 1, gx = xx + hx - 1;
+      goff[i] = (unsigned)((tid & 3) * 16);
+      if (pix >= C3_NPIX) zmask |= 0x101u << i;
+      else if (gy < 0 || gy >= p.H || gx < 0 || gx >= p.W) zmask |= 1u << i;
+      else {
+        const int spix = p.in_ups ? (gy >> 1) * Ws + (gx >> 1) : gy * Ws + gx;
+        goff[i] = (unsigned)((spix * (int)p.ldx + (tid & 3) * 8) * 2);
+      }
     }
-  }
-  const int nchunks = p.Cin >> 5;
+    return im;
+  };
+  // per-channel coefficients of the staging transform -> pads of the patch pixels (see c3_tab_off); block-uniform call
+  auto load_table = [&](int im) {
+    if (TF == 1) {
+      const float4* src = (const float4*)(p.tf_coef + (long)im * p.Cin * 2);
+      for (int j = tid; j < p.Cin / 2; j += 256) *(float4*)(smem + c3_tab_off(j)) = src[j];
+    } else if (TF == 2) {
+      const float4* src = (const float4*)(p.tf_coef + (long)im * p.Cin * 4);
+      for (int j = tid; j < p.Cin; j += 256) *(float4*)(smem + c3_tab_off(j)) = src[j];
+    }
+    tab_img = im;
+  };
 
-  // ---- staging of chunk c+1 under the MFMAs of chunk c.  Vector i is requested at tap i (i = 0..5) and transformed +
-  // written to the other patch buffer at tap i+3: three stage times (~1.5k cycles) cover the HBM latency.  The loads are
-  // inline asm so that hipcc neither waits for them itself (next to LDS-DMA traffic it would drain the whole queue with
-  // vmcnt(0)) nor touches their destination registers before the counted wait at the top of the consuming stage.
-  u32x4 sa[3], sb[TF == 2 ? 3 : 1];
-#pragma unroll
-  for (int j = 0; j < 3; ++j) sa[j] = (u32x4){0, 0, 0, 0};
-#pragma unroll
-  for (int j = 0; j < (TF == 2 ? 3 : 1); ++j) sb[j] = (u32x4){0, 0, 0, 0};
-  auto vec_load_asm = [&](int cbytes, int i) {      // chunk byte offset (c * 64), vector i -> register set i % 3
+  // ---- staging of the NEXT chunk under the MFMAs of the current one.  Vector i is requested at tap i (i = 0..5) and
+  // transformed + written to the other patch buffer at tap i+3: three stage times (~2k cycles) cover the HBM latency.  The
+  // loads are inline asm so that hipcc neither waits for them itself (next to LDS-DMA traffic it would drain the whole queue
+  // with vmcnt(0)) nor touches their destination registers before the counted wait at the top of the consuming stage.
+  // (TF 2 stages two tensors: it keeps two vectors per tensor in flight (written 2 stages after the request) instead of three,
+  // the third set did not fit the register file next to the transform's temporaries)
+  constexpr int DIST = TF == 2 ? 2 : 3;
+  u32x4 sa[3], sb[3];                                // (unused sets are dead code)
+  auto vec_load_asm = [&](int cbytes, int i) {      // chunk byte offset (chunk * 64), vector i -> register set i % DIST
     const unsigned off = goff[i] + (unsigned)cbytes;
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(sa[i % 3]) : "v"(off), "s"(ximg) : "memory");
-    if (TF == 2) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(sb[i % 3]) : "v"(off), "s"(x2img) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(sa[i % DIST]) : "v"(off), "s"(ximg) : "memory");
+    if (TF == 2) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(sb[i % DIST]) : "v"(off), "s"(x2img) : "memory");
   };
   auto transform = [&](int c, int i, uint4 o, uint4 o2) -> uint4 {
     if (TF == 1) {
@@ -186,23 +221,22 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
     if ((zmask >> i) & 1) o = make_uint4(0, 0, 0, 0);      // conv zero padding applies to the TRANSFORMED tensor
     return o;
   };
-  auto vec_store = [&](int c, int i, uint4 o) {      // branch free: lanes outside the patch (vector 5, tid >= 80) write a dummy slot
+  auto vec_store = [&](int buf, int i, uint4 o) {    // branch free: lanes outside the patch (vector 5, tid >= 80) write a dummy slot
     const int pix = (tid + i * 256) >> 2;
-    int addr = (c & 1) * C3_ABUF + pix * C3_PIXB + (tid & 3) * 16;
+    int addr = buf * C3_ABUF + pix * C3_PIXB + (tid & 3) * 16;
     if (i * 256 + 255 >= C3_NPIX * 4) addr = ((zmask >> (8 + i)) & 1) ? C3_LDS + (tid & 3) * 16 : addr;
     *(uint4*)(smem + addr) = o;
   };
 
   // ---- weight stream: stage (chunk c, tap t) = k-steps 2c, 2c+1 of tap t, n-tiles 4 nb .. 4 nb + 3, ring slot t % 3
-  // (9 taps per chunk: the slot of stage 9c + t is t % 3)
-  // The DMAs are inline asm as well: next to a builtin LDS-DMA hipcc drains the whole memory queue (vmcnt(0)) in front of
-  // the next ds_read of the same LDS object, i.e. once per stage.  M0 (the LDS destination base) is saved / restored around
-  // the two transfers; address = wave-uniform stage base (SGPR pair) + this thread's constant 32-bit byte offset.
-  const long kStride = (long)p.ntilesN * 64, tapStride = (long)(p.Cin >> 4) * kStride;     // in 16-byte units
-  const unsigned w_voff = (unsigned)((nb * 256 + tid) * 16);
+  // (9 taps per chunk: the slot of stage 9c + t is t % 3, also across tile boundaries).  The DMAs are inline asm as well: next
+  // to a builtin LDS-DMA hipcc drains the whole memory queue (vmcnt(0)) in front of the next ds_read of the same LDS object,
+  // i.e. once per stage.  M0 (the LDS destination base) is saved / restored around the two transfers; address = wave-uniform
+  // stage base (SGPR pair) + this thread's constant 32-bit byte offset.
+  const unsigned w_voff = (unsigned)(tid * 16);
   const unsigned lds_b = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem + 2 * C3_ABUF + wave * 1024;
-  auto dma_b = [&](int c, int tap, int slot) {
-    const uint4* g0 = p.wp + tap * tapStride + (long)(2 * c) * kStride;
+  auto dma_b = [&](int nb_, int c, int tap, int slot) {
+    const uint4* g0 = p.wp + (long)nb_ * 256 + tap * tapStride + (long)(2 * c) * kStride;
     const uint4* g1 = g0 + kStride;
     const unsigned l0 = lds_b + slot * C3_BSLOT, l1 = l0 + 4096;
     unsigned keep;
@@ -211,275 +245,368 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
                  : "=&s"(keep) : "v"(w_voff), "s"(g0), "s"(g1), "s"(l0), "s"(l1) : "memory");
   };
 
-  // accumulators start at the bias (lane (pixel, h) owns channels nt*32 + 8q + 4h + j in registers 4q + j): no bias pass later
-  f32x16 acc[4][2];
+  const int a_lane = (wm * 4 * C3_PW + (lane & 31)) * C3_PIXB + (lane >> 5) * 16;   // + (mt + ty) * PW * PIXB + tx * PIXB + ks * 32
+  const int b_lane = 2 * C3_ABUF + (wn * 2 * 64 + lane) * 16;                       // + slot * BSLOT + (ks * 4 + nt) * 1024
+  constexpr int NV = TF == 2 ? 2 : 1;                  // staging loads per vector
+  // The epilogue reads a second tensor (residual / GroupNorm input of the produced gradient) whose HBM latency would sit exposed
+  // behind the last MFMA: every chunk, taps 6 and 7 (no staging loads there) touch the two 128-byte lines of this thread's tile
+  // pixel, so the epilogue's loads are served by L2 / Infinity Cache.  Results are discarded; the loads are counted like the others.
+  constexpr bool AUXPF = C3_AUX_PREFETCH && (RES || STM == 2);
+  unsigned pf0 = 0, pf1 = 0;
+  const int cpg = p.Cout >> 5;
+
+  // ---- prologue of the block's FIRST tile: weight stages 0 and 1 in flight; coefficient table -> pads; the whole first patch
+  // (compiler-managed loads) into patch buffer 0
   {
-    const int hb = lane >> 5;
+    const int nb0 = cur % p.nblkN;
+    dma_b(nb0, 0, 0, 0);
+    dma_b(nb0, nchunks > 1 || true ? 0 : 0, 1, 1);
+    const int im = set_staging(cur);
+    if (TF) { load_table(im); __syncthreads(); }
+    uint4 o[C3_MAXV], o2[C3_MAXV];
+#pragma unroll
+    for (int i = 0; i < C3_MAXV; ++i) {
+      o[i] = *(const uint4*)((const char*)ximg + goff[i]);
+      o2[i] = make_uint4(0, 0, 0, 0);
+      if (TF == 2) o2[i] = *(const uint4*)((const char*)x2img + goff[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < C3_MAXV; ++i) vec_store(0, i, transform(0, i, o[i], o2[i]));
+  }
+  int pb = 0;                                            // patch buffer that holds chunk 0 of the current tile
+  bool first = true;
+  uint4 pa[4];                                           // k-step-0 patch fragments of the next stage (carried across stage barriers)
+
+  for (;;) {
+    // ---- current tile
+    const int mtile = cur / p.nblkN, nb = cur - mtile * p.nblkN;
+    const int img = mtile / tpi, trem = mtile - img * tpi;
+    const int ty0 = trem / p.tilesX;
+    const int y0 = ty0 * C3_TH, x0 = (trem - ty0 * p.tilesX) * C3_TW;
+    const int nxt = cur + nper;
+    const bool has_next = nxt < xend;
+    const int nb_n = has_next ? nxt % p.nblkN : nb;
+    if (first) C3_STAMP(1);
+
+    // accumulators start at the bias (lane (pixel, h) owns channels nt*32 + 8q + 4h + j in registers 4q + j): no bias pass later.
+    // (Lane-derived values of the tile prologue / epilogue come from an opaque copy of the thread index: otherwise hipcc hoists
+    // every such address out of the tile loop and keeps it live across the K loop -- hundreds of bytes of spills.)
+    int tv = threadIdx.x;
+    asm volatile("" : "+v"(tv));
+    const bf16_t* aux_img = p.y;      // image base of the tensor the epilogue reads (wave-uniform) + this thread's pixel offset
+    unsigned aux_off = 0;
+    if (AUXPF) {
+      const int py = y0 + ((tv >> 5) & 7), px = x0 + (tv & 31);
+      if (RES) {
+        const int Hr = p.res_ups ? p.H >> 1 : p.H, Wr = p.res_ups ? p.W >> 1 : p.W;
+        aux_img = p.res + (long)img * Hr * Wr * p.ldr + nb * C3_BN;
+        aux_off = (unsigned)(((p.res_ups ? (py >> 1) * Wr + (px >> 1) : py * Wr + px) * (int)p.ldr) * 2);
+      } else {
+        aux_img = p.st_x + (long)img * p.H * p.W * p.st_ldx + nb * C3_BN;
+        aux_off = (unsigned)(((py * p.W + px) * (int)p.st_ldx) * 2);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { sa[j] = (u32x4){0, 0, 0, 0}; sb[j] = (u32x4){0, 0, 0, 0}; }
+    pf0 = 0; pf1 = 0;     // new definitions: nothing of the staging
+                                                                                                   // registers lives across the epilogue
+    f32x16 acc[4][2];
+    {
+    const int h = (tv >> 5) & 1;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.bias) bq = *(const float4*)(p.bias + nb * C3_BN + wn * 64 + nt * 32 + 8 * q + 4 * hb);
+        if (p.bias) bq = *(const float4*)(p.bias + nb * C3_BN + wn * 64 + nt * 32 + 8 * q + 4 * h);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
           acc[mt][nt][4 * q + 0] = bq.x; acc[mt][nt][4 * q + 1] = bq.y; acc[mt][nt][4 * q + 2] = bq.z; acc[mt][nt][4 * q + 3] = bq.w;
         }
       }
-  }
+    }
 
-  // ---- prologue: weight stages 0 and 1 in flight; coefficient table -> pads; the whole first patch (compiler-managed loads)
-  dma_b(0, 0, 0);
-  dma_b(0, 1, 1);
-  if (TF == 1) {
-    const float4* src = (const float4*)(p.tf_coef + (long)img * p.Cin * 2);
-    for (int j = tid; j < p.Cin / 2; j += 256) *(float4*)(smem + c3_tab_off(j)) = src[j];
-    __syncthreads();
-  } else if (TF == 2) {
-    const float4* src = (const float4*)(p.tf_coef + (long)img * p.Cin * 4);
-    for (int j = tid; j < p.Cin; j += 256) *(float4*)(smem + c3_tab_off(j)) = src[j];
-    __syncthreads();
-  }
-#pragma unroll
-  for (int i = 0; i < C3_MAXV; ++i) {
-    const uint4 o = *(const uint4*)((const char*)ximg + goff[i]);
-    uint4 o2 = make_uint4(0, 0, 0, 0);
-    if (TF == 2) o2 = *(const uint4*)((const char*)x2img + goff[i]);
-    vec_store(0, i, transform(0, i, o, o2));
-  }
-
-  C3_STAMP(1);
-  const int a_lane = (wm * 4 * C3_PW + (lane & 31)) * C3_PIXB + (lane >> 5) * 16;   // + (mt + ty) * PW * PIXB + tx * PIXB + ks * 32
-  const int b_lane = 2 * C3_ABUF + (wn * 2 * 64 + lane) * 16;                       // + slot * BSLOT + (ks * 4 + nt) * 1024
-  constexpr int NV = TF == 2 ? 2 : 1;                  // staging loads per vector
-
-  // Per stage (chunk c, tap t), every wave issues, in this order: 2 weight DMAs (stage s+2), then NV staging loads if t < 6.
-  // At the top of stage s the weights of stage s (issued at s-2) and the staging vector written in this stage (issued at s-3)
-  // must have landed; still allowed in flight: the staging loads of s-2 and everything of s-1
-  //   -> vmcnt(2 + nv(t-1) + nv(t-2)), nv(t) = NV for t < 6 else 0 (taps wrap within the 9-tap chunk).
-  // The raw s_barrier that follows (a) publishes every wave's landed DMA of stage s and the patch writes of earlier stages
-  // (lgkmcnt(0) in the same wait), (b) guarantees all waves are done reading ring slot (s-1) % 3 before it is refilled.
-#define C3_NVT(t) (((t) + 9) % 9 < 6 ? NV : 0)
-  for (int c = 0; c < nchunks; ++c) {
-    const unsigned char* ab = smem + (c & 1) * C3_ABUF + a_lane;
-    const int cn = c + 1 < nchunks ? c + 1 : c;                 // last chunk: redundant re-loads keep the counts uniform (results unused)
-    auto stage = [&](auto tapc) {
-      constexpr int tap = decltype(tapc)::value;
-      // lgkmcnt(0) (the patch writes of taps 3..8 visible to the other waves) is only needed before the chunk's first stage;
-      // draining the LDS queue in front of every barrier exposed the latency of the fragment reads hipcc hoists there
-      constexpr bool LG = tap == 0 || C3_STRICT_LGKM;
-      if (TF == 2) {
-        if (LG) asm volatile("s_waitcnt vmcnt(%6) lgkmcnt(0)" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sa[2]), "+v"(sb[0]), "+v"(sb[TF == 2 ? 1 : 0]), "+v"(sb[TF == 2 ? 2 : 0])
-                         : "n"(2 + C3_NVT(tap - 1) + C3_NVT(tap - 2)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%6)" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sa[2]), "+v"(sb[0]), "+v"(sb[TF == 2 ? 1 : 0]), "+v"(sb[TF == 2 ? 2 : 0])
-                          : "n"(2 + C3_NVT(tap - 1) + C3_NVT(tap - 2)) : "memory");
-      } else {
-        if (LG) asm volatile("s_waitcnt vmcnt(%3) lgkmcnt(0)" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sa[2]) : "n"(2 + C3_NVT(tap - 1) + C3_NVT(tap - 2)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%3)" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sa[2]) : "n"(2 + C3_NVT(tap - 1) + C3_NVT(tap - 2)) : "memory");
+    // Per stage (chunk c, tap t), every wave issues, in this order: 2 weight DMAs (stage s+2), then NV staging loads if t < 6.
+    // At the top of stage s the weights of stage s (issued at s-2) and the staging vector written in this stage (issued at
+    // s-3) must have landed; still allowed in flight: the staging loads of s-2 and everything of s-1
+    //   -> vmcnt(2 + nv(t-1) + nv(t-2)), nv(t) = NV for t < 6 else 0 (taps wrap within the 9-tap chunk); with DIST = 2 the vector
+    //   written in stage s was requested at s-2 AFTER that stage's DMAs, so only stage s-1 may be in flight: vmcnt(2 + nv(t-1)).
+    // The first stage of a continued tile follows an epilogue with compiler-managed loads / stores in the queue: it drains
+    // everything (vmcnt(0)).  The raw s_barrier that follows the wait (a) publishes every wave's landed DMA of stage s and the
+    // patch writes of earlier stages, (b) guarantees all waves are done reading ring slot (s-1) % 3 before it is refilled.
+#define C3_NVT(t) (((t) + 9) % 9 < 6 ? NV : ((AUXPF && ((t) + 9) % 9 < 8) ? 1 : 0))
+    if (!first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile boundary: the epilogue's stores / loads leave the queue
+    for (int c = 0; c < nchunks; ++c) {
+      const bool last = c + 1 == nchunks;
+      if (last && has_next) {                            // from here on the staging loads belong to the next tile
+        const int im = set_staging(nxt);
+        if (TF && im != tab_img) {                       // (rare: the block's next tile lies in another image)
+          asm volatile("; C3_RARE_BEGIN\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();                  // every wave is past its last transform of the current image
+          load_table(im);
+          asm volatile("; C3_RARE_END" ::: "memory");
+        }
       }
-      __builtin_amdgcn_s_barrier();
-      {
-        const int t2 = tap + 2 >= 9 ? tap + 2 - 9 : tap + 2;
-        const int c2 = tap + 2 >= 9 ? cn : c;
-        dma_b(c2, t2, t2 % 3);
-      }
-      if (tap >= 3) {               // (last chunk: the other buffer is dead, the redundant write is harmless and keeps the stage branch free)
-        const int i = tap - 3;
-        const uint4 o = __builtin_bit_cast(uint4, sa[i % 3]);
-        const uint4 o2 = TF == 2 ? __builtin_bit_cast(uint4, sb[TF == 2 ? i % 3 : 0]) : make_uint4(0, 0, 0, 0);
-        vec_store(c + 1, i, transform(cn, i, o, o2));
-      }
-      if (tap < C3_MAXV) vec_load_asm(cn * 64, tap);      // (last chunk: re-reads chunk c, L2-hot, results unused)
-      const unsigned char* bb = smem + b_lane + (tap % 3) * C3_BSLOT;
-      const int toff = ((tap / 3) * C3_PW + (tap % 3)) * C3_PIXB;
+      const unsigned char* ab = smem + ((pb + c) & 1) * C3_ABUF + a_lane;
+      const int nbuf = (pb + c + 1) & 1;                 // patch buffer being staged
+      const int cn = last ? (has_next ? 0 : c) : c + 1;  // chunk index (within its tile) being staged (no next tile: redundant re-loads keep the counts uniform)
+      const int wc = last ? (has_next ? 0 : c) : c + 1, wnb = last ? nb_n : nb;     // chunk / n-block of the weight stages that wrap
+      auto stage = [&](auto tapc) {
+        constexpr int tap = decltype(tapc)::value;
+        // lgkmcnt(0) (patch writes of taps 3..8 visible to the other waves) is only needed before a chunk's first stage;
+        // draining the LDS queue in front of every barrier exposed the latency of the fragment reads hipcc hoists there
+        constexpr bool LG = tap == 0 || C3_STRICT_LGKM;
+        constexpr int NW = 2 + C3_NVT(tap - 1) + (DIST == 3 ? C3_NVT(tap - 2) : 0);
+        if (TF == 2) {
+          if (LG) asm volatile("s_waitcnt vmcnt(%6) lgkmcnt(0)" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sb[0]), "+v"(sb[1]), "+v"(pf0), "+v"(pf1) : "n"(NW) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%6)" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sb[0]), "+v"(sb[1]), "+v"(pf0), "+v"(pf1) : "n"(NW) : "memory");
+        } else {
+          if (LG) asm volatile("s_waitcnt vmcnt(%5) lgkmcnt(0)" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sa[2]), "+v"(pf0), "+v"(pf1) : "n"(NW) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%5)" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sa[2]), "+v"(pf0), "+v"(pf1) : "n"(NW) : "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        {
+          constexpr int t2 = tap + 2 >= 9 ? tap + 2 - 9 : tap + 2;
+          if (tap + 2 >= 9) dma_b(wnb, wc, t2, t2 % 3); else dma_b(nb, c, t2, t2 % 3);
+        }
+        if (tap >= DIST && tap < DIST + C3_MAXV) {   // (no next tile: the other buffer is dead, the redundant write is harmless and keeps the stage branch free)
+          constexpr int i = tap >= DIST ? tap - DIST : 0;
+          const uint4 o = __builtin_bit_cast(uint4, sa[i % DIST]);
+          const uint4 o2 = TF == 2 ? __builtin_bit_cast(uint4, sb[i % DIST]) : make_uint4(0, 0, 0, 0);
+          vec_store(nbuf, i, transform(cn, i, o, o2));
+        }
+        if (tap < C3_MAXV) vec_load_asm(cn * 64, tap);
+        if (AUXPF && tap == 6) asm volatile("global_load_dword %0, %1, %2" : "=v"(pf0) : "v"(aux_off), "s"(aux_img) : "memory");
+        if (AUXPF && tap == 7) asm volatile("global_load_dword %0, %1, %2 offset:128" : "=v"(pf1) : "v"(aux_off), "s"(aux_img) : "memory");
+        // explicit software pipeline of the fragment reads: the k-step-0 patch fragments of stage s+1 are requested under the
+        // k-step-1 MFMAs of stage s (same chunk: the patch buffer is stable) and carried across the barrier in pa[]; only the
+        // weight fragments wait for the barrier (their DMA is published by it)
+        const unsigned char* bb = smem + b_lane + (tap % 3) * C3_BSLOT;
+        constexpr int toff = ((tap / 3) * C3_PW + (tap % 3)) * C3_PIXB;
+        constexpr int toffn = (((tap + 1) / 3) * C3_PW + ((tap + 1) % 3)) * C3_PIXB;
+        if (tap == 0) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        uint4 bf[2], af[4];
+          for (int mt = 0; mt < 4; ++mt) pa[mt] = *(const uint4*)(ab + mt * C3_PW * C3_PIXB + toff);
+        }
+        uint4 b0[2], b1[2], a1[4];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) bf[nt] = *(const uint4*)(bb + (ks * 4 + nt) * 1024);
+        for (int nt = 0; nt < 2; ++nt) b0[nt] = *(const uint4*)(bb + nt * 1024);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) af[mt] = *(const uint4*)(ab + mt * C3_PW * C3_PIXB + toff + ks * 32);
+        for (int mt = 0; mt < 4; ++mt) a1[mt] = *(const uint4*)(ab + mt * C3_PW * C3_PIXB + toff + 32);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) b1[nt] = *(const uint4*)(bb + (4 + nt) * 1024);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma_bf16(bf[nt], af[mt], acc[mt][nt]);
-      }
-    };
-    stage(std::integral_constant<int, 0>{}); stage(std::integral_constant<int, 1>{}); stage(std::integral_constant<int, 2>{});
-    stage(std::integral_constant<int, 3>{}); stage(std::integral_constant<int, 4>{}); stage(std::integral_constant<int, 5>{});
-    stage(std::integral_constant<int, 6>{}); stage(std::integral_constant<int, 7>{}); stage(std::integral_constant<int, 8>{});
-  }
-#undef C3_NVT
-  // drain the redundant tail loads / DMAs before their registers and LDS are reused; all waves past their last fragment reads
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  C3_STAMP(2);
-  if (C3_ABL_NOEPI) {     // timing ablation: keep the accumulators live, skip the epilogue
-    float t = 0.f;
+          for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma_bf16(b0[nt], pa[mt], acc[mt][nt]);
+        if (tap < 8) {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) t += acc[mt][nt][r];
-    if (t == 12345.678f) p.y[0] = (bf16_t)1;
-    return;
-  }
-  // ---- epilogue (no LDS traffic until the statistics combine).  Addresses = wave-uniform 64-bit row bases + one 32-bit
-  // per-lane byte offset per tensor (saddr + voffset loads / stores: no 64-bit vector arithmetic).  A lane owns, for its pixel,
-  // channel quads 8q + 4h + {0..3} of each n-tile; residual / GroupNorm-input rows are fetched up front as 16-byte vectors in
-  // the STORE layout (lane h: channels 16k + 8h .. +7) -- 32 contiguous bytes per pixel per instruction, all 16 loads in flight
-  // at once -- and brought to the accumulator layout with the inverse of the store's v_permlane32_swap pairing.
-  const int h = lane >> 5, pl = lane & 31;
-  const int cpg = p.Cout >> 5;
-  const int nbase = nb * C3_BN + wn * 64;                 // first channel of this wave
-  const int row0 = y0 + wm * 4;                           // first pixel row of this wave
-  char* const yb = (char*)(p.y + ((long)img * p.H + row0) * p.W * p.ldy + nbase);
-  const unsigned rsy = (unsigned)(p.W * p.ldy * 2), lane_y = (unsigned)(((x0 + pl) * p.ldy + 8 * h) * 2);
-  uint4 aux[4][2][2];                                     // [mt][nt][k]: residual (RES) or GroupNorm input (STM 2) vectors
-  if (RES) {
-    const int Hr = p.res_ups ? p.H >> 1 : p.H, Wr = p.res_ups ? p.W >> 1 : p.W;
-    const char* const rb = (const char*)(p.res + (long)img * Hr * Wr * p.ldr + nbase);
-    const unsigned rsr = (unsigned)(Wr * p.ldr * 2), lane_r = (unsigned)((((p.res_ups ? (x0 + pl) >> 1 : x0 + pl)) * p.ldr + 8 * h) * 2);
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const char* r = rb + (unsigned)(p.res_ups ? (row0 + mt) >> 1 : row0 + mt) * rsr + lane_r;
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int k = 0; k < 2; ++k) aux[mt][nt][k] = *(const uint4*)(r + (nt * 32 + 16 * k) * 2);
-    }
-  } else if (STM == 2) {
-    const char* const xb = (const char*)(p.st_x + ((long)img * p.H + row0) * p.W * p.st_ldx + nbase);
-    const unsigned rsx = (unsigned)(p.W * p.st_ldx * 2), lane_x = (unsigned)(((x0 + pl) * p.st_ldx + 8 * h) * 2);
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int k = 0; k < 2; ++k) aux[mt][nt][k] = *(const uint4*)(xb + mt * rsx + lane_x + (nt * 32 + 16 * k) * 2);
-  }
-  float ss[16];                                           // [0..7]: sum 1 per (nt, quad), [8..15]: sum 2
-#pragma unroll
-  for (int i = 0; i < 16; ++i) ss[i] = 0.f;
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int cq = nbase + nt * 32 + 16 * k + 4 * h;    // quad 2k: channels cq .. cq+3; quad 2k+1: cq+8 .. cq+11
-      const unsigned coff = (unsigned)((nt * 32 + 16 * k) * 2);
-      float4 ka[4];                                       // mode 2: (a, b) of the 8 channels
-      float gm[2], gr[2];
-      if (STM == 2) {
-        const float4* cc = (const float4*)(p.st_coef + ((long)img * p.Cout + cq) * 2);
-        ka[0] = cc[0]; ka[1] = cc[1]; ka[2] = cc[4]; ka[3] = cc[5];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const float2 m = *(const float2*)(p.st_mr + ((long)img * 32 + (cq + 8 * q) / cpg) * 2);
-          gm[q] = m.x; gr[q] = m.y;
+          for (int mt = 0; mt < 4; ++mt) pa[mt] = *(const uint4*)(ab + mt * C3_PW * C3_PIXB + toffn);
         }
-      }
-      float t1[2] = {0.f, 0.f}, t2[2] = {0.f, 0.f};
-      f32x2 t1v[2] = {{0.f, 0.f}, {0.f, 0.f}}, t2v[2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma_bf16(b1[nt], a1[mt], acc[mt][nt]);
+        if (C3_SCHED_GROUPS && TF == 0) {
+        // pin the issue order of this region: all fragment reads of the stage first (their LDS latency then hides under the
+        // MFMAs carried over from the previous stage and the k-step-0 MFMAs), the next stage's patch fragments under k-step 1
+        __builtin_amdgcn_sched_group_barrier(0x100, tap == 0 ? 12 : 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        if (tap < 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        }
+      };
+      stage(std::integral_constant<int, 0>{}); stage(std::integral_constant<int, 1>{}); stage(std::integral_constant<int, 2>{});
+      stage(std::integral_constant<int, 3>{}); stage(std::integral_constant<int, 4>{}); stage(std::integral_constant<int, 5>{});
+      stage(std::integral_constant<int, 6>{}); stage(std::integral_constant<int, 7>{}); stage(std::integral_constant<int, 8>{});
+    }
+#undef C3_NVT
+    pb = (pb + nchunks) & 1;
+    if (first) C3_STAMP(2);
+
+    if (C3_ABL_NOEPI) {     // timing ablation: keep the accumulators live, skip the epilogue
+      float t = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) t += acc[mt][nt][r];
+      if (t == 12345.678f) p.y[0] = (bf16_t)1;
+    } else {
+    // ---- epilogue (LDS only for the statistics combine, in its own region).  Addresses = wave-uniform 64-bit row bases + one
+    // 32-bit per-lane byte offset per tensor (saddr + voffset loads / stores: no 64-bit vector arithmetic).  A lane owns, for its
+    // pixel, channel quads 8q + 4h + {0..3} of each n-tile; residual / GroupNorm-input rows are fetched up front as 16-byte
+    // vectors in the STORE layout (lane h: channels 16k + 8h .. +7) -- 32 contiguous bytes per pixel per instruction, all 16
+    // loads in flight at once -- and brought to the accumulator layout with the inverse of the store's v_permlane32_swap pairing.
+    int te = threadIdx.x;
+    asm volatile("" : "+v"(te));
+    const int h = (te >> 5) & 1, pl = te & 31;
+    const int nbase = nb * C3_BN + wn * 64;                 // first channel of this wave
+    const int row0 = y0 + wm * 4;                           // first pixel row of this wave
+    char* const yb = (char*)(p.y + ((long)img * p.H + row0) * p.W * p.ldy + nbase);
+    const unsigned rsy = (unsigned)(p.W * p.ldy * 2), lane_y = (unsigned)(((x0 + pl) * p.ldy + 8 * h) * 2);
+    uint4 aux[4][2][2];                                     // [mt][nt][k]: residual (RES) or GroupNorm input (STM 2) vectors
+    uint4 wst[STM == 2 ? 4 : 1][2][2];                      // STM 2: the stored (packed bf16) output vectors, store layout
+    if (RES) {
+      const int Hr = p.res_ups ? p.H >> 1 : p.H, Wr = p.res_ups ? p.W >> 1 : p.W;
+      const char* const rb = (const char*)(p.res + (long)img * Hr * Wr * p.ldr + nbase);
+      const unsigned rsr = (unsigned)(Wr * p.ldr * 2), lane_r = (unsigned)((((p.res_ups ? (x0 + pl) >> 1 : x0 + pl)) * p.ldr + 8 * h) * 2);
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
-        float v[8];
+        const char* r = rb + (unsigned)(p.res_ups ? (row0 + mt) >> 1 : row0 + mt) * rsr + lane_r;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = acc[mt][nt][8 * k + e];
-        uint32_t u0 = 0, u1 = 0, u2 = 0, u3 = 0;          // aux in the accumulator layout: (u0, u1) = quad 2k, (u2, u3) = quad 2k+1
-        if (RES || STM == 2) {
-          const uint4 a4 = aux[mt][nt][k];
-          auto r = __builtin_amdgcn_permlane32_swap(a4.x, a4.z, false, false);
-          u0 = r[0]; u2 = r[1];
-          r = __builtin_amdgcn_permlane32_swap(a4.y, a4.w, false, false);
-          u1 = r[0]; u3 = r[1];
-        }
-        if (RES) {
-          v[0] += bf_lo(u0); v[1] += bf_hi(u0); v[2] += bf_lo(u1); v[3] += bf_hi(u1);
-          v[4] += bf_lo(u2); v[5] += bf_hi(u2); v[6] += bf_lo(u3); v[7] += bf_hi(u3);
-        }
-        uint32_t w0x = pack_bf16x2(v[0], v[1]), w0y = pack_bf16x2(v[2], v[3]);
-        uint32_t w1x = pack_bf16x2(v[4], v[5]), w1y = pack_bf16x2(v[6], v[7]);
-        if (STM == 1) {     // statistics of the fp32 values (before the bf16 rounding of the store), two lanes of packed fp32 math
-          t1v[0] += (f32x2){v[0], v[1]}; t1v[0] += (f32x2){v[2], v[3]};
-          t2v[0] += (f32x2){v[0], v[1]} * (f32x2){v[0], v[1]}; t2v[0] += (f32x2){v[2], v[3]} * (f32x2){v[2], v[3]};
-          t1v[1] += (f32x2){v[4], v[5]}; t1v[1] += (f32x2){v[6], v[7]};
-          t2v[1] += (f32x2){v[4], v[5]} * (f32x2){v[4], v[5]}; t2v[1] += (f32x2){v[6], v[7]} * (f32x2){v[6], v[7]};
-        } else if (STM == 2) {
-          const float* dy = v;                             // (fp32 values, before the rounding of the store)
-          const float xg[8] = {bf_lo(u0), bf_hi(u0), bf_lo(u1), bf_hi(u1), bf_lo(u2), bf_hi(u2), bf_lo(u3), bf_hi(u3)};
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float4 kk = ka[e >> 1];
-            const float a = (e & 1) ? kk.z : kk.x, b = (e & 1) ? kk.w : kk.y;
-            const float z = a * xg[e] + b;
-            const float adz = a * (dy[e] * silu_grad_fast(z));
-            t1[e >> 2] += adz;
-            t2[e >> 2] += adz * xg[e];
+          for (int k = 0; k < 2; ++k) aux[mt][nt][k] = *(const uint4*)(r + (nt * 32 + 16 * k) * 2);
+      }
+    } else if (STM == 2) {
+      // GroupNorm-input rows in the STORE layout; they are consumed in the second sweep below, so their latency hides under
+      // the pack / store sweep
+      const char* const xb = (const char*)(p.st_x + ((long)img * p.H + row0) * p.W * p.st_ldx + nbase);
+      const unsigned rsx = (unsigned)(p.W * p.st_ldx * 2), lane_x = (unsigned)(((x0 + pl) * p.st_ldx + 8 * h) * 2);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int k = 0; k < 2; ++k) aux[mt][nt][k] = *(const uint4*)(xb + mt * rsx + lane_x + (nt * 32 + 16 * k) * 2);
+    }
+    float ss[16];                                           // [0..7]: sum 1 per channel quad, [8..15]: sum 2
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ss[i] = 0.f;
+    // ---- sweep 1: (residual,) pack, forward statistics, store
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const unsigned coff = (unsigned)((nt * 32 + 16 * k) * 2);
+        f32x2 t1v[2] = {{0.f, 0.f}, {0.f, 0.f}}, t2v[2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = acc[mt][nt][8 * k + e];
+          if (RES) {          // residual vector -> accumulator layout: (u0, u1) = quad 2k, (u2, u3) = quad 2k+1
+            const uint4 a4 = aux[mt][nt][k];
+            auto r = __builtin_amdgcn_permlane32_swap(a4.x, a4.z, false, false);
+            const uint32_t u0 = r[0], u2 = r[1];
+            r = __builtin_amdgcn_permlane32_swap(a4.y, a4.w, false, false);
+            const uint32_t u1 = r[0], u3 = r[1];
+            v[0] += bf_lo(u0); v[1] += bf_hi(u0); v[2] += bf_lo(u1); v[3] += bf_hi(u1);
+            v[4] += bf_lo(u2); v[5] += bf_hi(u2); v[6] += bf_lo(u3); v[7] += bf_hi(u3);
+          }
+          uint32_t w0x = pack_bf16x2(v[0], v[1]), w0y = pack_bf16x2(v[2], v[3]);
+          uint32_t w1x = pack_bf16x2(v[4], v[5]), w1y = pack_bf16x2(v[6], v[7]);
+          if (STM == 1) {     // statistics of the fp32 values (before the bf16 rounding of the store), two lanes of packed fp32 math
+            t1v[0] += (f32x2){v[0], v[1]}; t1v[0] += (f32x2){v[2], v[3]};
+            t2v[0] += (f32x2){v[0], v[1]} * (f32x2){v[0], v[1]}; t2v[0] += (f32x2){v[2], v[3]} * (f32x2){v[2], v[3]};
+            t1v[1] += (f32x2){v[4], v[5]}; t1v[1] += (f32x2){v[6], v[7]};
+            t2v[1] += (f32x2){v[4], v[5]} * (f32x2){v[4], v[5]}; t2v[1] += (f32x2){v[6], v[7]} * (f32x2){v[6], v[7]};
+          }
+          // lanes l and l + 32 hold the same pixel: after the swaps lanes < 32 own channels 16k .. 16k+7 and lanes >= 32
+          // own 16k+8 .. 16k+15 of their n-tile -> one 16-byte store each
+          {
+            auto r = __builtin_amdgcn_permlane32_swap(w0x, w1x, false, false);
+            w0x = r[0]; w1x = r[1];
+            r = __builtin_amdgcn_permlane32_swap(w0y, w1y, false, false);
+            w0y = r[0]; w1y = r[1];
+          }
+          const uint4 o = make_uint4(w0x, w0y, w1x, w1y);
+          *(uint4*)(yb + mt * rsy + coff + lane_y) = o;
+          if (STM == 2) wst[STM == 2 ? mt : 0][nt][k] = o;
+        }
+        if (STM == 1) {     // quad index nt*4 + 2k (+1) = channels nt*32 + 16k + 4h (+8) .. +3
+          ss[nt * 4 + 2 * k] = t1v[0][0] + t1v[0][1]; ss[8 + nt * 4 + 2 * k] = t2v[0][0] + t2v[0][1];
+          ss[nt * 4 + 2 * k + 1] = t1v[1][0] + t1v[1][1]; ss[8 + nt * 4 + 2 * k + 1] = t2v[1][0] + t2v[1][1];
+        }
+      }
+    }
+    if (first) C3_STAMP(4);
+    // ---- sweep 2 (backward statistics), in the STORE layout: this lane's vector (nt, k) = channels nt*32 + 16k + 8h .. +7 of
+    // its pixel, from the stored (rounded) dy and the GroupNorm input; the accumulators are dead, so the silu' chains have room.
+    // Quad index nt*4 + 2k (+1) = channels nt*32 + 16k + 8h (+4) .. +3.
+    if (STM == 2) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int cs = nbase + nt * 32 + 16 * k + 8 * h;
+          const float4* cc = (const float4*)(p.st_coef + ((long)img * p.Cout + cs) * 2);
+          const float4 ka[4] = {cc[0], cc[1], cc[2], cc[3]};           // (a, b) of the 8 channels
+          float t1[2] = {0.f, 0.f}, t2[2] = {0.f, 0.f};
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            const uint4 wd = wst[STM == 2 ? mt : 0][nt][k], wx = aux[mt][nt][k];
+            const float dy[8] = {bf_lo(wd.x), bf_hi(wd.x), bf_lo(wd.y), bf_hi(wd.y), bf_lo(wd.z), bf_hi(wd.z), bf_lo(wd.w), bf_hi(wd.w)};
+            const float xg[8] = {bf_lo(wx.x), bf_hi(wx.x), bf_lo(wx.y), bf_hi(wx.y), bf_lo(wx.z), bf_hi(wx.z), bf_lo(wx.w), bf_hi(wx.w)};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float4 kk = ka[e >> 1];
+              const float a = (e & 1) ? kk.z : kk.x, b = (e & 1) ? kk.w : kk.y;
+              const float z = a * xg[e] + b;
+              const float adz = a * (dy[e] * silu_grad_fast(z));
+              t1[e >> 2] += adz;
+              t2[e >> 2] += adz * xg[e];
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const float2 m = *(const float2*)(p.st_mr + ((long)img * 32 + (cs + 4 * q) / cpg) * 2);
+            ss[nt * 4 + 2 * k + q] = t1[q];
+            ss[8 + nt * 4 + 2 * k + q] = (t2[q] - m.x * t1[q]) * m.y;      // sum a*dz*xhat over this lane's values
           }
         }
-        // lanes l and l + 32 hold the same pixel: after the swaps lanes < 32 own channels 16k .. 16k+7 and lanes >= 32
-        // own 16k+8 .. 16k+15 of their n-tile -> one 16-byte store each
-        {
-          auto r = __builtin_amdgcn_permlane32_swap(w0x, w1x, false, false);
-          w0x = r[0]; w1x = r[1];
-          r = __builtin_amdgcn_permlane32_swap(w0y, w1y, false, false);
-          w0y = r[0]; w1y = r[1];
-        }
-        *(uint4*)(yb + mt * rsy + coff + lane_y) = make_uint4(w0x, w0y, w1x, w1y);
-        if (STM == 2) __builtin_amdgcn_sched_barrier(0);  // one pixel row at a time: 32 interleaved silu' chains would not fit the register file
-      }
-      if (STM == 1) {
-        ss[nt * 4 + 2 * k] = t1v[0][0] + t1v[0][1]; ss[8 + nt * 4 + 2 * k] = t2v[0][0] + t2v[0][1];
-        ss[nt * 4 + 2 * k + 1] = t1v[1][0] + t1v[1][1]; ss[8 + nt * 4 + 2 * k + 1] = t2v[1][0] + t2v[1][1];
-      } else if (STM == 2) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          ss[nt * 4 + 2 * k + q] = t1[q];
-          ss[8 + nt * 4 + 2 * k + q] = (t2[q] - gm[q] * t1[q]) * gr[q];     // sum a*dz*xhat over this lane's values
-        }
       }
     }
-  }
-  if (STM) {
-    // 16 partial sums per lane, 32 pixel lanes per half-wave: butterfly reduce-scatter (8 + 4 + 2 + 1 exchanges, then one
-    // plain exchange) leaves value j = bits (4,3,2,1) of the lane index, summed over the half-wave, in every lane
+    if (first) C3_STAMP(5);
+    if (STM) {
+      // 16 partial sums per lane, 32 pixel lanes per half-wave: butterfly reduce-scatter (8 + 4 + 2 + 1 exchanges, then one
+      // plain exchange) leaves value j = bits (4,3,2,1) of the lane index, summed over the half-wave, in every lane
 #pragma unroll
-    for (int st_ = 0; st_ < 4; ++st_) {
-      const int off = 16 >> st_, n = 8 >> st_;            // partner distance, values kept
-      const bool up = (pl & off) != 0;
+      for (int st_ = 0; st_ < 4; ++st_) {
+        const int off = 16 >> st_, n = 8 >> st_;            // partner distance, values kept
+        const bool up = (pl & off) != 0;
 #pragma unroll
-      for (int j = 0; j < n; ++j) {
-        const float send = up ? ss[j] : ss[j + n];
-        const float keep = up ? ss[j + n] : ss[j];
-        ss[j] = keep + __shfl_xor(send, off, 64);
+        for (int j = 0; j < n; ++j) {
+          // (opaque copies: hipcc otherwise folds `up ? ss[j] : ss[j+n]` into a lane-indexed access of the register array,
+          // i.e. a 16-way compare / select chain per access -- 1600 instructions, 6 us per tile)
+          float lo = ss[j], hi = ss[j + n];
+          asm volatile("" : "+v"(lo), "+v"(hi));
+          const float send = up ? lo : hi;
+          const float keep = up ? hi : lo;
+          ss[j] = keep + __shfl_xor(send, off, 64);
+        }
       }
-    }
-    ss[0] += __shfl_xor(ss[0], 1, 64);
-    float* sred = (float*)smem;                           // [wave][h][16]; the patch buffers are dead (barrier after the K loop)
-    if ((pl & 1) == 0) sred[(wave * 2 + h) * 16 + (pl >> 1)] = ss[0];
-    __syncthreads();
-    if (tid < 64) {
-      // tid -> (wn', h', j): j < 8: sum 1 of quad j = nt * 4 + q, j >= 8: sum 2
-      const int wn2 = tid >> 5, h2 = (tid >> 4) & 1, j = tid & 15;
-      const float a = sred[((0 * 2 + wn2) * 2 + h2) * 16 + j] + sred[((1 * 2 + wn2) * 2 + h2) * 16 + j];
-      const int i = j & 7;
-      const int ch = nb * C3_BN + wn2 * 64 + (i >> 2) * 32 + (i & 3) * 8 + 4 * h2;
+      ss[0] += __shfl_xor(ss[0], 1, 64);
+      float* sred = (float*)(smem + C3_LDS + 64);           // [wave][h][16], own LDS region (the patch buffers hold the next tile)
+      if ((pl & 1) == 0) sred[(wave * 2 + h) * 16 + (pl >> 1)] = ss[0];
+      if (first) C3_STAMP(7);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // LDS only: a __syncthreads() here would also wait for the output stores
+      __builtin_amdgcn_s_barrier();
+      if (tid < 64) {
+        // tid -> (wn', h', j): j < 8: sum 1 of quad j = nt * 4 + q, j >= 8: sum 2
+        const int wn2 = tid >> 5, h2 = (tid >> 4) & 1, j = tid & 15;
+        const float a = sred[((0 * 2 + wn2) * 2 + h2) * 16 + j] + sred[((1 * 2 + wn2) * 2 + h2) * 16 + j];
+        const int i = j & 7;          // quad (nt = i >> 2, 2k + q = i & 3): accumulator layout (mode 1) or store layout (mode 2)
+        const int ch = nb * C3_BN + wn2 * 64 + (i >> 2) * 32 + (STM == 2 ? ((i >> 1) & 1) * 16 + 8 * h2 + (i & 1) * 4 : (i & 3) * 8 + 4 * h2);
 #if C3_ABL_NOATOM
-      if (a == 12345.678f) p.st_sums[0] = a;
+        if (a == 12345.678f) p.st_sums[0] = a;
 #else
-      atomicAdd(p.st_sums + ((long)img * 32 + ch / cpg) * 2 + (j >> 3), (double)a);
+        atomicAdd(p.st_sums + ((long)img * 32 + ch / cpg) * 2 + (j >> 3), (double)a);
 #endif
+      }
+      // (sred is rewritten by the next tile's epilogue only after a full K loop of stage barriers)
     }
+    }
+    if (first) C3_STAMP(3);
+    first = false;
+    if (!has_next) break;
+    cur = nxt;
   }
-  C3_STAMP(3);
-#if C3_TIMING
-  if (p.dbg && threadIdx.x == 0) {
-    p.dbg[(long)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // HW_REG_XCC_ID
-    p.dbg[(long)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID (wave / simd / cu / sh / se)
-  }
-#endif
+  // drain the redundant tail loads / DMAs before the wave ends
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  C3_STAMP(6);
 }
 
 template <int TF, int STM, bool RES>
@@ -490,11 +617,20 @@ int launch3(const Conv3Params& p, hipStream_t st) {
   KDIP_HIP_CHECK(hipGetDevice(&dev));
   const unsigned long long bit = 1ull << (dev & 63);
   if (!(granted.load(std::memory_order_acquire) & bit)) {
-    KDIP_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS + 64));
+    KDIP_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS_TOTAL));
     granted.fetch_or(bit, std::memory_order_release);
   }
-  const long grid = (long)p.mtiles * p.nblkN;
-  hipLaunchKernelGGL(kern, dim3((unsigned)((grid + 7) / 8 * 8)), dim3(256), C3_LDS + 64, st, p);
+  // persistent launch: two resident blocks per CU (VGPR / LDS budget of the kernel), a multiple of 8 (one share per XCD)
+  static std::atomic<int> num_cu{0};
+  if (!num_cu.load()) {
+    int n = 0;
+    KDIP_HIP_CHECK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    num_cu.store(n > 0 ? n : 256);
+  }
+  const long ntiles8 = ((long)p.mtiles * p.nblkN + 7) / 8 * 8;
+  long grid = (long)C3_BLOCKS_PER_CU * num_cu.load() / 8 * 8;
+  if (grid > ntiles8) grid = ntiles8;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), C3_LDS_TOTAL, st, p);
   return KDIP_OK;
 }
 

@@ -9,7 +9,8 @@ a = [int(v) for v in sys.argv[1:]]
 B, Cin, Cout, H, W = a[:5]
 tf = a[5] if len(a) > 5 else 0; stm = a[6] if len(a) > 6 else 0; res = a[7] if len(a) > 7 else 0
 lib = L.load()
-grid = ((B * (H // 8) * (W // 32) * (Cout // 128) + 7) // 8) * 8
+ntiles = B * (H // 8) * (W // 32) * (Cout // 128)
+grid = min(((ntiles + 7) // 8) * 8, 512)          # persistent launch: 2 blocks per CU
 buf = torch.zeros(grid, 8, dtype=torch.int64, device="cuda")
 g = torch.Generator().manual_seed(0)
 x = torch.randn(B, Cin, H, W, generator=g); w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5; b = torch.randn(Cout, generator=g)
@@ -25,17 +26,9 @@ t = buf.cpu().numpy().astype(np.int64)
 t = t[t[:, 0] > 0]
 t0 = t[:, 0].min()
 us = lambda v: v / 100.0
-pro, kl, epi, life = us(t[:, 1] - t[:, 0]), us(t[:, 2] - t[:, 1]), us(t[:, 3] - t[:, 2]), us(t[:, 3] - t[:, 0])
-print(f"blocks {len(t)}; launch span {us(t[:, 3].max() - t0):.1f} us")
-for name, v in (("prologue", pro), ("K loop", kl), ("epilogue", epi), ("block life", life)):
+pro, kl, epi, life = us(t[:, 1] - t[:, 0]), us(t[:, 2] - t[:, 1]), us(t[:, 3] - t[:, 2]), us(t[:, 6] - t[:, 0])
+tpb = ntiles / len(t)
+print(f"persistent blocks {len(t)} ({tpb:.2f} tiles each); launch span {us(t[:, 6].max() - t0):.1f} us; later tiles: {((life - us(t[:, 3] - t[:, 0])) / max(tpb - 1, 1e-9)).mean():.2f} us per tile")
+e1, e2, e3 = us(t[:, 4] - t[:, 2]), us(t[:, 5] - t[:, 4]), us(t[:, 3] - t[:, 5])
+for name, v in (("prologue 1", pro), ("K loop 1", kl), ("epilogue 1", epi), ("  sweep 1 (loads, pack, store)", e1), ("  sweep 2 (bwd stats)", e2), ("  stats combine", e3), ("    of which reduce-scatter", us(np.maximum(t[:, 7] - t[:, 5], 0))), ("block life", life)):
     print(f"  {name:10s} mean {v.mean():7.2f}  p10 {np.percentile(v, 10):7.2f}  p50 {np.percentile(v, 50):7.2f}  p90 {np.percentile(v, 90):7.2f} us")
-# co-residency: blocks per CU key (xcc, se/sh/cu bits of HW_ID) and the phase offset between co-resident blocks
-key = (t[:, 4] & 0xf) * 65536 + ((t[:, 5] >> 8) & 0xffff)
-start = us(t[:, 0] - t0)
-order = np.argsort(start)
-print("  start-time histogram (us):", np.histogram(start, bins=12)[0].tolist(), "edges", [round(e) for e in np.histogram(start, bins=12)[1].tolist()])
-cus = {}
-for i in order: cus.setdefault(key[i], []).append((start[i], us(t[i, 3] - t0)))
-print("  distinct CU keys:", len(cus))
-k0 = list(cus.keys())[0]
-print("  timeline of one CU (start, end):", [(round(a, 1), round(b, 1)) for a, b in cus[k0]][:12])
