@@ -238,30 +238,44 @@ def main():
         import csv, tempfile, collections
         dump = os.environ.get("KDIP_PROFILE_DUMP") or os.path.join(tempfile.gettempdir(), f"kdip_conv_dump_{os.getpid()}.csv")
         L.check(lib.kdip_profile_dump(dump.encode()))
-        grp = collections.defaultdict(lambda: [0, 0.0, 0.0])
+        grp = collections.defaultdict(lambda: [0, 0.0, 0.0, 0.0])
         for r in csv.DictReader(open(dump)):
             if not r["class"].startswith("conv"):
                 continue
-            key = (r["class"], r["d0"], r["d1"], r["d2"], r["d3"])
-            grp[key][0] += 1; grp[key][1] += float(r["us"]); grp[key][2] += float(r["gflop"])
-        key, (cnt, us, gf) = max(grp.items(), key=lambda kv: kv[1][1])
+            key = (r["class"], r["tag"], r["d0"], r["d1"], r["d2"], r["d3"])
+            grp[key][0] += 1; grp[key][1] += float(r["us"]); grp[key][2] += float(r["gflop"]); grp[key][3] += float(r["mbytes"])
+        key, (cnt, us, gf, mb) = max(grp.items(), key=lambda kv: kv[1][1])
         tflops = gf / us * 1e3 if us > 0 else 0.0          # GFLOP / us = PFLOP/s
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_conv3x3_latest.json")   # rocprofv3 --pmc passes on the same kernel + shape
+        # HBM traffic of this (kernel, fusion mode, layer shape): rocprofv3 --pmc passes over the same in-network launches
+        # (tools/pmc_innetwork.sh -> profiles/r02_pmc_innetwork.json; FETCH_SIZE x 2 + WRITE_SIZE per MI355X_MICROARCH.md)
+        traffic, traffic_source, pmc_extra = None, None, {}
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_innetwork.json")
         if os.path.exists(pmc):
             try:
-                pj = json.load(open(pmc))
-                if pj.get("shape_key") == "|".join(key):
-                    traffic = pj.get("hbm_bytes_per_launch_bf16_out")
+                e = json.load(open(pmc))["shapes"].get("|".join(key[1:]))
+                if e:
+                    traffic = e.get("hbm_bytes_per_launch")
+                    traffic_source = ("profiles/r02_pmc_innetwork.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the in-network launches "
+                                      "of this kernel + fusion mode + layer shape (tools/pmc_innetwork.sh on one guided Heun step of this workload); "
+                                      "not re-measured in this run")
+                    pmc_extra = {k: e[k] for k in ("traffic_over_algorithmic", "mfma_busy_frac", "shader_clock_ghz", "lds_bank_conflict_frac_of_lds_active",
+                                                   "l2_hit_rate") if k in e}
             except Exception:
                 traffic = None
+        fusion = {"conv3": "plain", "conv3_gnf": "GroupNorm+SiLU fused into the input staging", "conv3_gnb": "GroupNorm backward fused into the input staging"}
+        tagparts = key[1].split("_")
+        base = "_".join(tagparts[:2]) if len(tagparts) > 1 and tagparts[1] in ("gnf", "gnb") else tagparts[0]
+        desc = fusion.get(base, "first-generation kernel (conv.hip)") + ("; GroupNorm forward sums of the output in the epilogue" if "s1" in tagparts else "") + \
+            ("; GroupNorm backward sums of the output in the epilogue" if "s2" in tagparts else "") + ("; residual add" if "res" in tagparts else "")
         names = [lib.kdip_profile_class_name(j).decode() for j in range(n)]
         k = max((j for j in range(n) if names[j].startswith("conv")), key=lambda j: ms[j])
         out["roofline"] = {
-            "kernel": f"{key[0]} (conv_igemm_kernel<bf16,9,2,2,2,2,1>, v_mfma_f32_32x32x16_bf16), layer B={key[1]} {key[3]}->{key[4]} ch @ {key[2]}x{key[2]}",
+            "kernel": f"{key[1]} ({'conv3_kernel, csrc/conv3.hip' if key[1].startswith('conv3') else 'conv_igemm_kernel, csrc/conv.hip'}, v_mfma_f32_32x32x16_bf16: {desc}), "
+                      f"layer B={key[2]} {key[4]}->{key[5]} ch @ {key[3]}x{key[3]}",
             "bound": "mfma", "achieved": round(tflops, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(tflops / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+            "frac": round(tflops / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source, "pmc_in_network": pmc_extra,
             "launches": cnt, "avg_launch_us": round(us / cnt, 2), "algorithmic_gflop_per_launch": round(gf / cnt, 3),
+            "algorithmic_bytes_per_launch": round(mb / cnt * 1e6),
             "share_of_profiled_conv_time": round(us / max(sum(v[1] for v in grp.values()), 1e-9), 3),
             "class_aggregate": {"kernel_class": lib.kdip_profile_class_name(k).decode(), "tflops": round(fl[k] / max(ms[k], 1e-9) / 1e9, 2),
                                 "launches": int(la[k]), "avg_launch_us": round(ms[k] * 1e3 / max(la[k], 1), 2)},

@@ -681,7 +681,14 @@ p.dbg = C3_TIMING ? g_c3_dbg : nullptr;
   if (g_prof_on) {
     const double px = (double)B * H * W;
     const int cr = cin_real > 0 ? cin_real : Cin;
-    prof_begin(st, PC_CONV3_128x128, 2.0 * px * cr * Cout * 9, px * (cr + Cout) * 2.0 + 9.0 * cr * Cout * 2.0, tf ? (tf == 1 ? "conv3_gnf" : "conv3_gnb") : "conv3", B, H, cr, Cout);
+    // tag = conv3[_gnf|_gnb][_s1|_s2][_res]; algorithmic bytes = every tensor the launch must read / write once
+    static const char* tags[3][3][2] = {{{"conv3", "conv3_res"}, {"conv3_s1", "conv3_s1_res"}, {"conv3_s2", "conv3_s2_res"}},
+                                        {{"conv3_gnf", "conv3_gnf_res"}, {"conv3_gnf_s1", "conv3_gnf_s1_res"}, {"conv3_gnf_s2", "conv3_gnf_s2_res"}},
+                                        {{"conv3_gnb", "conv3_gnb_res"}, {"conv3_gnb_s1", "conv3_gnb_s1_res"}, {"conv3_gnb_s2", "conv3_gnb_s2_res"}}};
+    const double in_px = p.in_ups ? px / 4 : px, res_px = p.res_ups ? px / 4 : px;
+    const double bytes = in_px * cr * 2.0 * (tf == 2 ? 2 : 1) + 9.0 * cr * Cout * 2.0 + px * Cout * 2.0 + (res ? res_px * Cout * 2.0 : 0.0) +
+                         (stm == 2 ? px * Cout * 2.0 : 0.0);
+    prof_begin(st, PC_CONV3_128x128, 2.0 * px * cr * Cout * 9, bytes, tags[tf][stm][res ? 1 : 0], B, H, cr, Cout);
   }
   // instantiated combinations: forward convs (tf 0 / 1, statistics 0 / 1, with / without residual) and dgrad convs
   // (tf 0 / 2, statistics 0 / 2, never a residual)

@@ -71,11 +71,13 @@ class UNetModel:
         self.attention_ds = tuple(image_size // int(r) for r in str(attention_resolutions).split(","))
         self.dtype = dtype
         dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if dev.type == "cuda" and dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())       # explicit index: handles / workspaces live on ONE device
         self.device = dev
         h = C.c_void_p()
         ads = (C.c_int * len(self.attention_ds))(*self.attention_ds)
         cms = (C.c_int * len(self.channel_mult))(*self.channel_mult)
-        L.check(self.lib.kdip_unet_create(dev.index if dev.index is not None else torch.cuda.current_device(), L.BF16 if dtype == "bf16" else L.F32, image_size, in_channels,
+        L.check(self.lib.kdip_unet_create(dev.index, L.BF16 if dtype == "bf16" else L.F32, image_size, in_channels,
                                           model_channels, out_channels, num_res_blocks, ads, len(self.attention_ds),
                                           cms, len(self.channel_mult), num_head_channels, C.byref(h)))
         self._h = h
