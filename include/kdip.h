@@ -155,6 +155,21 @@ int kdip_profile_report(double* ms, double* flops, double* bytes, long* launches
 /* writes one CSV row per recorded launch (class, shape, algorithmic GFLOP / MB, microseconds). */
 int kdip_profile_dump(const char* path);
 
+/* ------------------------------------------------------------------ LPIPS
+ * The perceptual metric of compute_metrics (sample_condition_openai.py:41-49,161: lpips.LPIPS(net='vgg')): a stand-alone conv
+ * layer handle (the 13 VGG-16 convs of lpips/pretrained_networks.py:vgg16 run on the implicit-GEMM kernel), ReLU / 2x2 max
+ * pool on fp32 NCHW planes, and the per-layer distance  out[b] += mean_px sum_c w_c (f0_c/|f0| - f1_c/|f1|)^2
+ * (lpips.normalize_tensor, NetLinLayer, spatial_average).  Host side: kdip_amd/lpips.py. */
+typedef struct kdip_conv kdip_conv;
+int kdip_conv_create(int device, int dtype, const float* w_host /*[Cout][Cin][kh][kw]*/, const float* bias_host, int Cout, int Cin,
+                     int ntaps /*9 | 1*/, kdip_conv** out);
+void kdip_conv_destroy(kdip_conv* c);
+long kdip_conv_workspace_bytes(kdip_conv* c, int B, int H, int W);
+int kdip_conv_apply(kdip_conv* c, void* stream, const float* x_nchw_dev, int B, int H, int W, float* y_nchw_dev, void* workspace_dev);
+int kdip_relu_maxpool(void* stream, const float* x_dev, long planes, int H, int W, int pool, float* y_dev);
+int kdip_lpips_layer(void* stream, const float* f0_dev, const float* f1_dev, const float* lin_w_dev, int B, int C, long HW,
+                     float* out_accum_dev /*[B], += */);
+
 /* ------------------------------------------------------------------ low-level test hooks
  * (exercised by tests/ to localise kernel bugs; NHWC tensors of the UNet storage dtype) */
 int kdip_test_conv(void* stream, int dtype, int ntaps, const float* x_nchw_dev, int B, int Cin, int H, int W,

@@ -226,6 +226,53 @@ int kdip_test_conv(void* stream, int dtype, int ntaps, const float* x_nchw, int 
   return KDIP_OK;
 }
 
+// ------------------------------------------------------------------ stand-alone conv layers (LPIPS backbone) ----
+struct kdip_conv { DType dt; int cin, cout, cin_pad, ntaps, device; void* w = nullptr; float* bias = nullptr; };
+int kdip_conv_create(int device, int dtype, const float* w_host, const float* bias_host, int Cout, int Cin, int ntaps, kdip_conv** out) {
+  KDIP_REQUIRE(out && w_host && (ntaps == 9 || ntaps == 1) && Cout > 0 && Cin > 0, "conv_create: bad arguments");
+  KDIP_HIP_CHECK(hipSetDevice(device));
+  kdip_conv* c = new kdip_conv;
+  c->dt = dtype == KDIP_BF16 ? DT_BF16 : DT_F32; c->cin = Cin; c->cout = Cout; c->cin_pad = pad32i(Cin); c->ntaps = ntaps; c->device = device;
+  std::vector<char> buf(packed_weight_bytes(c->dt, ntaps, c->cin_pad, Cout));
+  pack_conv_weight(c->dt, w_host, Cout, Cin, ntaps, 0, c->cin_pad, buf.data());
+  if (hipMalloc(&c->w, buf.size()) != hipSuccess) { delete c; return set_error(KDIP_ERR_NOMEM, "conv_create: hipMalloc failed"); }
+  KDIP_HIP_CHECK(hipMemcpy(c->w, buf.data(), buf.size(), hipMemcpyHostToDevice));
+  if (bias_host) {
+    KDIP_HIP_CHECK(hipMalloc((void**)&c->bias, sizeof(float) * Cout));
+    KDIP_HIP_CHECK(hipMemcpy(c->bias, bias_host, sizeof(float) * Cout, hipMemcpyHostToDevice));
+  }
+  *out = c;
+  return KDIP_OK;
+}
+void kdip_conv_destroy(kdip_conv* c) {
+  if (!c) return;
+  if (c->w) (void)hipFree(c->w);
+  if (c->bias) (void)hipFree(c->bias);
+  delete c;
+}
+// y = conv(x) (+ bias); x [B,Cin,H,W] fp32 NCHW, y [B,Cout,H,W] fp32 NCHW; ws: caller-provided device scratch of
+// kdip_conv_workspace_bytes(c, B, H, W) bytes (no allocation here: capture-safe)
+long kdip_conv_workspace_bytes(kdip_conv* c, int B, int H, int W) {
+  if (!c) return -1;
+  const size_t es = c->dt == DT_BF16 ? 2 : 4;
+  return (long)(es * (size_t)B * H * W * c->cin_pad + sizeof(float) * (size_t)B * H * W * pad32i(c->cout) + 512);
+}
+int kdip_conv_apply(kdip_conv* c, void* stream, const float* x_nchw, int B, int H, int W, float* y_nchw, void* ws) {
+  KDIP_REQUIRE(c && x_nchw && y_nchw && ws, "conv_apply: null argument");
+  hipStream_t st = ST(stream);
+  const size_t es = c->dt == DT_BF16 ? 2 : 4;
+  char* xin = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  float* y32 = (float*)(xin + ((es * (size_t)B * H * W * c->cin_pad + 255) & ~(size_t)255));
+  const int opad = pad32i(c->cout);
+  API_CK(nchw_to_nhwc(st, c->dt, x_nchw, B, c->cin, H, W, 1.f, xin, c->cin_pad, c->cin_pad));
+  API_CK(conv_forward(st, c->dt, c->ntaps, xin, c->cin_pad, B, H, W, c->cin_pad, c->w, c->bias, c->cout, y32, opad, nullptr, 0, 1, 1.f, c->cin));
+  return nhwc_to_nchw_f32(st, y32, opad, B, c->cout, H, W, y_nchw);
+}
+int kdip_relu_maxpool(void* stream, const float* x, long planes, int H, int W, int pool, float* y) { return relu_maxpool_planes(ST(stream), x, planes, H, W, pool, y); }
+int kdip_lpips_layer(void* stream, const float* f0, const float* f1, const float* lin_w, int B, int C, long HW, float* out_accum) {
+  return lpips_layer(ST(stream), f0, f1, lin_w, B, C, HW, out_accum);
+}
+
 // conv3.hip through the C ABI: every tensor argument is a device fp32 NCHW tensor (converted to the bf16 NHWC storage
 // layout here), coefficient tables are device fp32 arrays in the layouts of Conv3Fuse; reps > 1 re-runs the conv and
 // reports the mean HIP-event time per launch in *avg_us_host.

@@ -214,4 +214,57 @@ int nhwc_T_to_nchw_f32(hipStream_t st, DType dt, const void* x, long ld, int B, 
   return KDIP_OK;
 }
 
+
+// ------------------------------------------------------------------ LPIPS (VGG) helpers ----
+// The perceptual metric of the caller harness (sample_condition_openai.py:46,161: lpips.LPIPS(net='vgg')) runs its 13 VGG convs
+// through conv_forward; these kernels are the glue on fp32 NCHW planes: ReLU (+ 2x2 max pool) and the per-layer distance.
+__global__ void relu_maxpool_planes_kernel(const float* __restrict__ x, long planes, int H, int W, int pool, float* __restrict__ y) {
+  const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
+  const long n = planes * Ho * Wo;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % Wo);
+    const long t = i / Wo;
+    const int oy = (int)(t % Ho);
+    const long pl = t / Ho;
+    const float* p = x + pl * H * W;
+    float v;
+    if (pool) v = fmaxf(fmaxf(p[(2 * oy) * W + 2 * ox], p[(2 * oy) * W + 2 * ox + 1]), fmaxf(p[(2 * oy + 1) * W + 2 * ox], p[(2 * oy + 1) * W + 2 * ox + 1]));
+    else v = p[oy * W + ox];
+    y[i] = fmaxf(v, 0.f);
+  }
+}
+int relu_maxpool_planes(hipStream_t st, const float* x, long planes, int H, int W, int pool, float* y) {
+  KDIP_REQUIRE(!pool || (H % 2 == 0 && W % 2 == 0), "maxpool2: odd plane size %dx%d", H, W);
+  const long n = planes * (pool ? H / 2 : H) * (pool ? W / 2 : W);
+  hipLaunchKernelGGL(relu_maxpool_planes_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x, planes, H, W, pool, y);
+  KDIP_LAUNCH_CHECK();
+  return KDIP_OK;
+}
+
+// out[b] += mean over pixels of sum_c w[c] * (f0[c] / (|f0| + eps) - f1[c] / (|f1| + eps))^2, |f| = sqrt(sum_c f[c]^2) per pixel
+// (lpips.normalize_tensor + lin layer + spatial_average); f0, f1: [B, C, HW] fp32.  One thread per pixel, coalesced over pixels.
+__global__ void lpips_layer_kernel(const float* __restrict__ f0, const float* __restrict__ f1, const float* __restrict__ w, int C, long HW,
+                                   float* __restrict__ out) {
+  const int b = blockIdx.y;
+  const float* a = f0 + (long)b * C * HW;
+  const float* c = f1 + (long)b * C * HW;
+  float acc = 0.f;
+  for (long px = (long)blockIdx.x * blockDim.x + threadIdx.x; px < HW; px += (long)gridDim.x * blockDim.x) {
+    float n0 = 0.f, n1 = 0.f;
+    for (int ch = 0; ch < C; ++ch) { const float u = a[ch * HW + px], v = c[ch * HW + px]; n0 += u * u; n1 += v * v; }
+    const float r0 = 1.f / (sqrtf(n0) + 1e-10f), r1 = 1.f / (sqrtf(n1) + 1e-10f);
+    float d = 0.f;
+    for (int ch = 0; ch < C; ++ch) { const float t = a[ch * HW + px] * r0 - c[ch * HW + px] * r1; d += w[ch] * t * t; }
+    acc += d;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out + b, acc / (float)HW);
+}
+int lpips_layer(hipStream_t st, const float* f0, const float* f1, const float* w, int B, int C, long HW, float* out) {
+  long g = (HW + 255) / 256; if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(lpips_layer_kernel, dim3((unsigned)g, B), dim3(256), 0, st, f0, f1, w, C, HW, out);
+  KDIP_LAUNCH_CHECK();
+  return KDIP_OK;
+}
+
 }  // namespace kdip

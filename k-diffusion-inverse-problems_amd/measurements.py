@@ -18,6 +18,25 @@ from . import _lib as L
 
 KERNEL_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kernels")
 
+
+_NOISE_RNG = "device"
+
+
+def set_noise_rng(where):
+    """'device' (default): measurement noise from the device generator (torch.randn_like on the HIP tensor).  'cpu': drawn from
+    torch's CPU generator and copied over -- the random stream of the reference's CPU path, so a harness run can be compared
+    value for value with a run of the reference (or of a CPU restatement of it) on the same seeds (sample_condition.py --cpu-rng)."""
+    global _NOISE_RNG
+    assert where in ("device", "cpu")
+    _NOISE_RNG = where
+
+
+def _randn_like(y):
+    if _NOISE_RNG == "cpu":
+        return torch.randn(y.shape, dtype=y.dtype).to(y.device)
+    return torch.randn_like(y)
+
+
 __OPERATOR__ = {}
 
 
@@ -177,7 +196,7 @@ class _BlurBase(_FFTModelMixin, LinearOperator):
     def forward(self, data, flatten=False, noiseless=False):
         y = self._apply(data, False, data.shape)
         if not noiseless:
-            y += self.sigma_s * torch.randn_like(y)
+            y += self.sigma_s * _randn_like(y)
         self._meas_for_pre = y
         if flatten:
             return y, y.reshape(y.shape[0], -1)
@@ -285,7 +304,7 @@ class SuperResolutionOperator(_FFTModelMixin, LinearOperator):
     def forward(self, data, flatten=False, noiseless=False):
         y = self._resize(data)
         if not noiseless:
-            y += self.sigma_s * torch.randn_like(y)
+            y += self.sigma_s * _randn_like(y)
         self._meas_for_pre = y
         if flatten:
             return y, y.reshape(y.shape[0], -1)
@@ -326,7 +345,7 @@ class InpaintingOperator(LinearOperator):
     def forward(self, data: torch.Tensor, flatten=False, noiseless=False):
         y = self._check(data)
         if not noiseless:
-            y = y + self.sigma_s * torch.randn_like(y)            # noise BEFORE masking (measurements.py:212-215)
+            y = y + self.sigma_s * _randn_like(y)                 # noise BEFORE masking (measurements.py:212-215)
         y = self._apply(y, False, y.shape)
         if flatten:
             B = y.shape[0]

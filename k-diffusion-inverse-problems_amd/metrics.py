@@ -3,8 +3,9 @@
 
 PSNR and SSIM are restated from their published definitions (skimage.metrics is not importable in
 the build container, so SSIM parity is *unpinned*: tests check it against an independent
-scipy.ndimage restatement of the same algorithm).  LPIPS needs the VGG checkpoint, which is not
-obtainable offline: the key is omitted from the metric dict rather than faked.
+scipy.ndimage restatement of the same algorithm).  LPIPS (kdip_amd.lpips.LPIPS, the VGG forward on the
+HIP conv kernels) is reported when a loaded `loss_fn_vgg` is passed, as in the reference; its pretrained
+weights are not obtainable offline, so without a checkpoint the key is omitted rather than faked.
 """
 import torch
 import torch.nn.functional as F
@@ -37,11 +38,14 @@ def structural_similarity(a, b, data_range=1.0, win_size=7, K1=0.01, K2=0.03):
     return float(S.mean())
 
 
-def compute_metrics(hat_x0, x0):
-    """{'psnr', 'ssim'} of the FIRST sample against the ground truth (the reference also reports
-    'lpips'; see the module docstring)."""
+def compute_metrics(hat_x0, x0, loss_fn_vgg=None):
+    """{'psnr', 'ssim'[, 'lpips']} of the FIRST sample against the ground truth (sample_condition_openai.py:41-49; lpips is
+    evaluated on the [0,1] images exactly as the reference calls it)."""
     a, b = to_eval(x0).cpu(), to_eval(hat_x0).cpu()
-    return {"psnr": peak_signal_noise_ratio(a, b, 1.0), "ssim": structural_similarity(a, b, 1.0)}
+    m = {"psnr": peak_signal_noise_ratio(a, b, 1.0), "ssim": structural_similarity(a, b, 1.0)}
+    if loss_fn_vgg is not None:
+        m["lpips"] = float(loss_fn_vgg(to_eval(x0), to_eval(hat_x0))[0, 0, 0, 0])
+    return m
 
 
 def calculate_average_metric(metrics_list):

@@ -15,7 +15,8 @@ constants :191, per-image metric dict + avg_metrics.yaml :196-213) on top of the
   * no checkpoint / dataset is obtainable offline, so `--synthetic-weights` (seeded random-init
     weights of the configured architecture) and `--synthetic-data N` (seeded smooth images) stand in
     for `--checkpoint` and the image folder; real ones are used when the paths exist.
-  * metrics: psnr + ssim (kdip_amd.metrics); lpips needs the VGG checkpoint and is omitted.
+  * metrics: psnr + ssim (kdip_amd.metrics) + lpips when `--lpips-checkpoint` names a VGG / lin state_dict (kdip_amd.lpips;
+    the pretrained weights are not obtainable offline).
   * one process per GPU: launch under `python -m torch.distributed.run` for multi-GPU; the samples of
     an image are split over the ranks and all-gathered once (kdip_amd.evaluation.compute_features).
 """
@@ -113,10 +114,16 @@ def main():
     p.add_argument("--synthetic-weights", action="store_true", help="seeded random-init weights when the checkpoint is absent")
     p.add_argument("--synthetic-data", type=int, default=0, metavar="N", help="N seeded smooth images when the dataset folder is absent")
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--lpips-checkpoint", type=str, default="", help="state_dict of lpips.LPIPS(net='vgg') (VGG-16 backbone + lin layers); "
+                   "'synthetic' = seeded random weights (exercises the path, the value is meaningless); empty = no lpips key")
+    p.add_argument("--cpu-rng", action="store_true", help="draw the measurement noise and x_T from torch's CPU generator (the random stream of "
+                   "the reference's CPU path): a run is then comparable value for value with a run of the reference on the same seeds")
     p.add_argument("--streams", type=int, default=1, help="split each sampler batch into this many part-batches, each with its own "
                    "UNet handle / operator context / HIP stream / host thread (overlaps HBM-bound and MFMA-bound phases)")
     args = p.parse_args()
 
+    if args.cpu_rng:
+        km.set_noise_rng("cpu")
     config = load_json(args.config)
     model_config, dataset_config = config["model"], config["dataset"]
     v2 = args.v2 or "ortho_tf_type" in model_config
@@ -138,7 +145,9 @@ def main():
     elif args.synthetic_weights:
         sd = ku.synthetic_state_dict(seed=args.seed, out_cov=v2, image_size=size[0], model_channels=model_config["openai"]["num_channels"],
                                      num_res_blocks=model_config["openai"]["num_res_blocks"],
-                                     attention_resolutions=model_config["openai"]["attention_resolutions"])
+                                     attention_resolutions=model_config["openai"]["attention_resolutions"],
+                                     **({"channel_mult": tuple(int(c) for c in model_config["openai"]["channel_mult"].split(","))}
+                                        if model_config["openai"].get("channel_mult") else {}))
     else:
         raise FileNotFoundError(f"checkpoint {args.checkpoint} not found (pass --synthetic-weights for random-init weights)")
     for m, _ in models:
@@ -178,6 +187,12 @@ def main():
             s = ks.get_sigmas_karras(1000, sigma_min, sigma_max, device="cpu")[:-1]
             recon_mse = {"sigmas": s, "mse_list": s ** 2 / (1 + s ** 2) * 0.5}
 
+    loss_fn_vgg = None
+    if args.lpips_checkpoint:
+        import kdip_amd.lpips as klp
+        loss_fn_vgg = klp.LPIPS(net="vgg", device=device)
+        loss_fn_vgg.load_state_dict(klp.synthetic_state_dict(args.seed) if args.lpips_checkpoint == "synthetic"
+                                    else torch.load(args.lpips_checkpoint, map_location="cpu"))
     metrics_list = []
     for i, x0 in enumerate(images):
         x0 = x0[None].to(device)
@@ -208,7 +223,10 @@ def main():
             return sampler()
 
         def sample_fn(n):
-            x = torch.randn([n, model_config["input_channels"], size[0], size[1]], device=device) * sigma_max
+            if args.cpu_rng:
+                x = torch.randn([n, model_config["input_channels"], size[0], size[1]]).to(device) * sigma_max
+            else:
+                x = torch.randn([n, model_config["input_channels"], size[0], size[1]], device=device) * sigma_max
             k = min(nstreams, n)
             if k == 1:
                 return sample_part(cond_models[0], x)
@@ -218,7 +236,7 @@ def main():
             return torch.cat(outs)
 
         hat_x0 = ke.compute_features(env, sample_fn, lambda x: x, args.n, args.batch_size)
-        metrics = kmet.compute_metrics(hat_x0, x0)
+        metrics = kmet.compute_metrics(hat_x0, x0, loss_fn_vgg)
         metrics_list.append(metrics)
         if env.is_main_process:
             print(i, metrics, flush=True)

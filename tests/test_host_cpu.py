@@ -237,10 +237,69 @@ def test_harness_config_loaders(tmp_path):
     exec(compile(src[src.index("def load_yaml"):src.index("def folder_of_images")], "loaders", "exec"), {"yaml": __import__("yaml"), "json": __import__("json")}, ns)
     t = ns["load_yaml"](os.path.join(root, "configs", "tasks.yaml#gaussian_deblur"))
     assert t == {"name": "gaussian_blur", "in_shape": [1, 3, 256, 256], "kernel_size": 61, "intensity": 3.0, "sigma_s": 0.05}
-    assert set(ns["load_yaml"](os.path.join(root, "configs", "tasks.yaml"))) == {"gaussian_deblur", "motion_deblur", "super_resolution_4x", "inpainting", "inpainting_box"}
+    assert set(ns["load_yaml"](os.path.join(root, "configs", "tasks.yaml"))) == {"gaussian_deblur", "motion_deblur", "super_resolution_4x", "inpainting", "inpainting_box", "gaussian_deblur_64", "inpainting_64"}
     m = ns["load_json"](os.path.join(root, "configs", "models.json#imagenet"))
     assert m["model"]["openai"] == {"num_channels": 256, "num_res_blocks": 2, "attention_resolutions": "8,16,32"}
     f = tmp_path / "one.yaml"
     f.write_text("name: super_resolution\nin_shape: !!python/tuple [1, 3, 256, 256]\nscale_factor: 4\nsigma_s: 0.05\n")
     one = ns["load_yaml"](str(f))
     assert one["in_shape"] == (1, 3, 256, 256) and one["scale_factor"] == 4
+
+
+# ------------------------------------------------------------------ dataset / checkpoint IO ----
+def test_folder_of_images_roundtrip(tmp_path):
+    """K.utils.FolderOfImages + ToTensor + (x*2-1) (k_diffusion/utils.py:274-297, sample_condition_openai.py:138-143): sorted
+    recursive listing, RGB conversion, [-1, 1] range; to_pil_image is its inverse up to 8-bit rounding."""
+    import numpy as np
+    from PIL import Image
+    import sample_condition as sc
+    rng = np.random.RandomState(0)
+    names = ["b/2.png", "a/1.png", "c.jpg", "a/0.bmp", "notes.txt"]
+    imgs = {}
+    for n in names:
+        p = tmp_path / n
+        p.parent.mkdir(parents=True, exist_ok=True)
+        if n.endswith(".txt"):
+            p.write_text("not an image")
+            continue
+        a = rng.randint(0, 256, size=(16, 16, 3), dtype=np.uint8)
+        Image.fromarray(a).save(p, quality=100) if n.endswith(".jpg") else Image.fromarray(a).save(p)
+        imgs[str(p)] = a
+    out = list(sc.folder_of_images(str(tmp_path)))
+    order = sorted(imgs)
+    assert len(out) == 4
+    for t, path in zip(out, order):
+        assert t.shape == (3, 16, 16) and t.dtype == torch.float32 and float(t.min()) >= -1 and float(t.max()) <= 1
+        if not path.endswith(".jpg"):                     # lossless formats round-trip exactly
+            back = np.asarray(sc.to_pil_image(t))
+            assert np.array_equal(back, imgs[path])
+    # grayscale / palette files are converted to RGB
+    Image.fromarray(rng.randint(0, 256, size=(8, 8), dtype=np.uint8), mode="L").save(tmp_path / "gray.png")
+    g = [t for t in sc.folder_of_images(str(tmp_path))]
+    assert all(t.shape[0] == 3 for t in g)
+
+
+def test_checkpoint_layouts_on_disk(tmp_path):
+    """The two checkpoint layouts the reference's scripts load (sample_condition_openai.py:130-132: a plain state_dict .pt;
+    sample_condition_openai_v2.py:116 / train_openai.py:86-87: a Lightning .ckpt whose 'state_dict' holds model_ema.inner_model.* and
+    model_ema.out_cov.* next to optimizer-side keys) written to disk, read back with torch.load and normalised to the key layout
+    kdip_unet_load expects."""
+    import kdip_amd.unet as ku
+    cfg = dict(image_size=64, model_channels=32, num_res_blocks=1, attention_resolutions="32", channel_mult=(1, 2))
+    sd = ku.synthetic_state_dict(seed=3, out_cov=True, **cfg)
+    plain = {k: v for k, v in sd.items() if not k.startswith("out_cov.")}
+    torch.save(plain, tmp_path / "diffusion.pt")
+    got = ku.normalize_state_dict(torch.load(tmp_path / "diffusion.pt", map_location="cpu"))
+    assert set(got) == set(plain) and all(torch.equal(got[k], plain[k]) for k in plain)
+    lightning = {"epoch": 3, "global_step": 1000, "pytorch-lightning_version": "2.0.0",
+                 "state_dict": {**{"model.inner_model." + k: v + 1 for k, v in plain.items()},                      # the non-EMA copy must be ignored
+                                **{"model_ema.inner_model." + k: v for k, v in plain.items()},
+                                **{"model_ema.out_cov." + k[len("out_cov."):]: v for k, v in sd.items() if k.startswith("out_cov.")},
+                                "model_ema.sigma_data": torch.tensor(0.5)},
+                 "optimizer_states": [{}]}
+    torch.save(lightning, tmp_path / "ffhq_dwt.ckpt")
+    got = ku.normalize_state_dict(torch.load(tmp_path / "ffhq_dwt.ckpt", map_location="cpu"))
+    assert set(got) == set(sd), sorted(set(got) ^ set(sd))[:5]
+    assert all(torch.equal(got[k], sd[k]) for k in sd)
+    shapes, _ = ku.state_dict_shapes(out_cov=True, **cfg)
+    assert all(tuple(got[k].shape) == tuple(shapes[k]) for k in shapes)

@@ -165,3 +165,24 @@ def test_unet_missing_weight_fails_loudly():
     m = ku.UNetModel(image_size=64, model_channels=32, num_res_blocks=1, attention_resolutions="32", channel_mult=(1, 2), dtype="f32")
     with pytest.raises(L.KdipError):
         m.load_state_dict(sd)
+
+
+def test_lpips_vgg_forward_synthetic_weights():
+    """kdip_amd.lpips.LPIPS (13 VGG convs on the implicit-GEMM kernel in f32 mode, ReLU / max-pool / per-layer distance kernels)
+    against the CPU restatement of the lpips package's forward on seeded synthetic weights (the pretrained ones are not obtainable
+    offline): relative error < 1e-4; bf16 mode within 3 %."""
+    import kdip_amd.lpips as klp
+    from oracle.lpips import lpips_vgg
+    sd = klp.synthetic_state_dict(0)
+    g = torch.Generator().manual_seed(1)
+    a = torch.rand(3, 64, 64, generator=g)
+    b = (a + 0.2 * torch.randn(3, 64, 64, generator=g)).clamp(0, 1)
+    ref = float(lpips_vgg(sd, a, b)[0, 0, 0, 0])
+    m = klp.LPIPS(net="vgg").load_state_dict(sd)
+    got = float(m(a, b)[0, 0, 0, 0])
+    assert abs(got - ref) / abs(ref) < 1e-4, (got, ref)
+    assert float(m(a, a)[0, 0, 0, 0]) == 0.0
+    got2 = m(torch.stack([a, b]), torch.stack([b, b])).flatten().tolist()       # batched call
+    assert abs(got2[0] - ref) / abs(ref) < 1e-4 and got2[1] == 0.0
+    mb = klp.LPIPS(net="vgg", dtype="bf16").load_state_dict(sd)
+    assert abs(float(mb(a, b)[0, 0, 0, 0]) - ref) / abs(ref) < 3e-2
