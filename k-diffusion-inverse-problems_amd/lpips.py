@@ -33,7 +33,7 @@ def synthetic_state_dict(seed=0):
 
 
 class LPIPS:
-    """loss = LPIPS(...)(in0, in1): in0 / in1 [3,H,W] or [B,3,H,W] (H, W powers of two >= 32); returns [B,1,1,1] like the package."""
+    """loss = LPIPS(...)(in0, in1): in0 / in1 [3,H,W] or [B,3,H,W] (H, W powers of two >= 128); returns [B,1,1,1] like the package."""
 
     def __init__(self, net="vgg", dtype="f32", device=None):
         if net != "vgg":
@@ -101,6 +101,9 @@ class LPIPS:
             raise L.KdipError("LPIPS: load_state_dict first (the pretrained weights are not bundled)")
         if in0.dim() == 3:
             in0, in1 = in0[None], in1[None]
+        H, W = in0.shape[-2:]
+        if in0.shape != in1.shape or H < 128 or W < 128 or (H & (H - 1)) or (W & (W - 1)):
+            raise L.KdipError(f"LPIPS: images must have equal power-of-two sizes >= 128 (got {tuple(in0.shape)}, {tuple(in1.shape)})")
         in0 = in0.to(self.device, torch.float32)
         in1 = in1.to(self.device, torch.float32)
         if normalize:                                 # [0,1] -> [-1,1] (the package's flag; the reference leaves it off)

@@ -20,6 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ("super_resolution_4x", ["--guidance", "II", "--xstart-cov-type", "pgdm"]),
     ("inpainting_box", ["--guidance", "dps+mle", "--xstart-cov-type", "convert", "--zeta", "1.0", "--ode"]),
     ("motion_deblur", ["--guidance", "I", "--xstart-cov-type", "analytic", "--ode"]),
+    ("gaussian_deblur", ["--guidance", "I", "--xstart-cov-type", "convert", "--ode", "--lpips-checkpoint", "synthetic"]),   # lpips key through kdip_amd.lpips
 ])
 def test_harness_runs(tmp_path, op, extra):
     logdir = str(tmp_path / "out")
@@ -31,7 +32,8 @@ def test_harness_runs(tmp_path, op, extra):
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     avg = yaml.safe_load(open(os.path.join(logdir, "avg_metrics.yaml")))
-    assert set(avg) == {"psnr", "ssim"} and all(v == v and abs(v) < 1e6 for v in avg.values()), avg
+    want = {"psnr", "ssim", "lpips"} if "--lpips-checkpoint" in extra else {"psnr", "ssim"}
+    assert set(avg) == want and all(v == v and abs(v) < 1e6 for v in avg.values()), avg
     assert os.path.exists(os.path.join(logdir, "args.yaml"))
     pngs = [f for f in os.listdir(logdir) if f.endswith(".png")]
     assert len(pngs) == 3, pngs          # 1 measurement + 2 samples

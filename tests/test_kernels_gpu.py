@@ -175,8 +175,8 @@ def test_lpips_vgg_forward_synthetic_weights():
     from oracle.lpips import lpips_vgg
     sd = klp.synthetic_state_dict(0)
     g = torch.Generator().manual_seed(1)
-    a = torch.rand(3, 64, 64, generator=g)
-    b = (a + 0.2 * torch.randn(3, 64, 64, generator=g)).clamp(0, 1)
+    a = torch.rand(3, 128, 128, generator=g)            # (>= 128: the last VGG slice runs on 1/16 resolution maps, the conv tiles need >= 8x8)
+    b = (a + 0.2 * torch.randn(3, 128, 128, generator=g)).clamp(0, 1)
     ref = float(lpips_vgg(sd, a, b)[0, 0, 0, 0])
     m = klp.LPIPS(net="vgg").load_state_dict(sd)
     got = float(m(a, b)[0, 0, 0, 0])
