@@ -155,6 +155,11 @@ int kdip_profile_report(double* ms, double* flops, double* bytes, long* launches
 /* writes one CSV row per recorded launch (class, shape, algorithmic GFLOP / MB, microseconds). */
 int kdip_profile_dump(const char* path);
 
+/* out[b] (+)= mean_i ((pred - target)^2 * exp(-logvar) + logvar): one half of OpenAIDenoiserV2.loss (k_diffusion/external.py:145-159);
+ * accumulate = 0 zeroes out[] first. */
+int kdip_gauss_nll_mean(void* stream, const float* pred_dev, const float* target_dev, const float* logvar_dev, int B, long per,
+                        int accumulate, float* out_dev);
+
 /* ------------------------------------------------------------------ LPIPS
  * The perceptual metric of compute_metrics (sample_condition_openai.py:41-49,161: lpips.LPIPS(net='vgg')): a stand-alone conv
  * layer handle (the 13 VGG-16 convs of lpips/pretrained_networks.py:vgg16 run on the implicit-GEMM kernel), ReLU / 2x2 max

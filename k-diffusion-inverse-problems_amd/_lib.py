@@ -50,6 +50,7 @@ SIGNATURES = {
     "kdip_sampler_add_noise": (C.c_int, [VP, VP, VP, C.c_float, C.c_long, VP]),
     "kdip_sampler_euler": (C.c_int, [VP, VP, VP, C.c_float, C.c_float, C.c_long, VP]),
     "kdip_sampler_heun": (C.c_int, [VP, VP, VP, VP, VP, C.c_float, C.c_float, C.c_float, C.c_long, VP]),
+    "kdip_gauss_nll_mean": (C.c_int, [VP, VP, VP, VP, C.c_int, C.c_long, C.c_int, VP]),
     "kdip_conv_create": (C.c_int, [C.c_int, C.c_int, VP, VP, C.c_int, C.c_int, C.c_int, C.POINTER(VP)]),
     "kdip_conv_destroy": (None, [VP]),
     "kdip_conv_workspace_bytes": (C.c_long, [VP, C.c_int, C.c_int, C.c_int]),

@@ -268,6 +268,9 @@ int kdip_conv_apply(kdip_conv* c, void* stream, const float* x_nchw, int B, int 
   API_CK(conv_forward(st, c->dt, c->ntaps, xin, c->cin_pad, B, H, W, c->cin_pad, c->w, c->bias, c->cout, y32, opad, nullptr, 0, 1, 1.f, c->cin));
   return nhwc_to_nchw_f32(st, y32, opad, B, c->cout, H, W, y_nchw);
 }
+int kdip_gauss_nll_mean(void* stream, const float* pred, const float* target, const float* logvar, int B, long per, int accumulate, float* out) {
+  return gauss_nll_mean(ST(stream), pred, target, logvar, B, per, accumulate, out);
+}
 int kdip_relu_maxpool(void* stream, const float* x, long planes, int H, int W, int pool, float* y) { return relu_maxpool_planes(ST(stream), x, planes, H, W, pool, y); }
 int kdip_lpips_layer(void* stream, const float* f0, const float* f1, const float* lin_w, int B, int C, long HW, float* out_accum) {
   return lpips_layer(ST(stream), f0, f1, lin_w, B, C, HW, out_accum);

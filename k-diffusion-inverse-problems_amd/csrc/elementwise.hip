@@ -267,4 +267,28 @@ int lpips_layer(hipStream_t st, const float* f0, const float* f1, const float* w
   return KDIP_OK;
 }
 
+
+// out[b] (+)= mean_i ((pred - target)^2 * exp(-logvar) + logvar) over the `per` elements of sample b: the two halves (pixel space,
+// transform space) of the DWT-Var / DCT-Var objective, OpenAIDenoiserV2.loss (k_diffusion/external.py:145-159)
+__global__ void gauss_nll_mean_kernel(const float* __restrict__ pred, const float* __restrict__ target, const float* __restrict__ logvar, long per,
+                                      int accumulate, float* __restrict__ out) {
+  const int b = blockIdx.y;
+  const float *p = pred + (long)b * per, *t = target + (long)b * per, *lv = logvar + (long)b * per;
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long)gridDim.x * blockDim.x) {
+    const float e = p[i] - t[i], l = lv[i];
+    acc += e * e * __expf(-l) + l;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out + b, acc / (float)per);
+  (void)accumulate;
+}
+int gauss_nll_mean(hipStream_t st, const float* pred, const float* target, const float* logvar, int B, long per, int accumulate, float* out) {
+  if (!accumulate) KDIP_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(float) * B, st));
+  long g = (per + 255) / 256; if (g > 256) g = 256;
+  hipLaunchKernelGGL(gauss_nll_mean_kernel, dim3((unsigned)g, B), dim3(256), 0, st, pred, target, logvar, per, accumulate, out);
+  KDIP_LAUNCH_CHECK();
+  return KDIP_OK;
+}
+
 }  // namespace kdip

@@ -105,6 +105,7 @@ int softmax_bwd_rows(hipStream_t st, DType dt, const void* p, const float* dp, l
 // LPIPS glue on fp32 NCHW planes: y = relu(maxpool2?(x)); out[b] += LPIPS distance of one layer (see elementwise.hip)
 int relu_maxpool_planes(hipStream_t st, const float* x, long planes, int H, int W, int pool, float* y);
 int lpips_layer(hipStream_t st, const float* f0, const float* f1, const float* w, int B, int C, long HW, float* out);
+int gauss_nll_mean(hipStream_t st, const float* pred, const float* target, const float* logvar, int B, long per, int accumulate, float* out);
 int silu_f32(hipStream_t st, const float* x, long n, float* y);
 int timestep_embedding(hipStream_t st, const float* t, int B, int dim, float* out);
 int f32_to_T(hipStream_t st, DType dt, const float* x, long n, void* y);

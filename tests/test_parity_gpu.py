@@ -467,3 +467,35 @@ def test_analytic_variance_estimator(gold, tiny):
     assert float((torch.tensor(out) - T(ga["mse_list"])).abs().max()) < 1e-4
     res = kav.estimate_recon_mse(models["f32"], D, [b.cuda() for b in batches], sigmas=sig)
     assert res["mse_list"].shape == (6,) and torch.isfinite(res["mse_list"]).all() and res["errors"].shape == (6, 2)
+
+
+@pytest.mark.parametrize("ortho", ["dwt", "dct"])
+def test_dwtvar_loss_value(tiny, ortho):
+    """OpenAIDenoiserV2.loss (k_diffusion/external.py:145-159), forward value: HIP path (f32 mode) against the formula restated on the
+    oracle UNet + oracle OrthoTransform, batch of 3 with two distinct sigmas."""
+    import torch.nn.functional as F
+    import kdip_amd.external as ke
+    from oracle import unet as ounet
+    from oracle.tables import DiffusionTables
+    from oracle.transforms import OrthoTransform as OOT
+    models, D, sd, cfg = tiny
+    g = torch.Generator().manual_seed(4)
+    x = (torch.rand(3, 3, 64, 64, generator=g) * 2 - 1) * 0.7
+    noise = torch.randn(3, 3, 64, 64, generator=g)
+    sigma = torch.tensor([0.5, 2.0, 0.5])
+    den = ke.OpenAIDenoiserV2(models["f32"], D, ortho_tf_type=ortho)
+    got = den.loss(x.cuda(), noise.cuda(), sigma.cuda()).cpu()
+    T_, ot = DiffusionTables(), OOT(ortho)
+    ref = []
+    for i in range(3):
+        s = sigma[i:i + 1]
+        c_in, c_out = 1 / (s ** 2 + 1) ** 0.5, -s
+        xn = x[i:i + 1] + noise[i:i + 1] * s
+        out, feat = ounet.unet_forward(sd, cfg, xn * c_in, T_.sigma_to_t(s), return_feature=True)
+        mo = out.chunk(2, dim=1)[0]
+        logvar, logvar_ot = F.conv2d(feat, sd["out_cov.weight"], sd["out_cov.bias"]).chunk(2, dim=1)
+        target = (x[i:i + 1] - xn) / c_out
+        loss = (mo - target).pow(2) / logvar.exp() + logvar + (ot(mo) - ot(target)).pow(2) / logvar_ot.exp() + logvar_ot
+        ref.append(float(loss.flatten(1).mean(1)))
+    ref = torch.tensor(ref)
+    assert float((got - ref).abs().max() / ref.abs().max()) < 2e-4, (got, ref)
