@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--no-large-batch", action="store_true", help="skip the extra throughput leg at batch 128 (N = 1 only)")
     ap.add_argument("--streams", type=int, default=2, help="part-batches per GPU, each on its own HIP stream + host thread")
     ap.add_argument("--dtype", choices=("bf16", "f32"), default="bf16", help="UNet storage / MFMA type (f32 = the exact-f32 parity mode)")
+    ap.add_argument("--no-graph-leg", action="store_true", help="skip the extra leg that replays the guided calls from hipGraphs (N = 1 only)")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the extra leg that times the same workload in the f32 parity mode (N = 1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -286,6 +287,28 @@ def main():
                                   for j in range(n) if la[j] > 0 and not names[j].startswith("conv")},
         }
         L.check(lib.kdip_profile_enable(0))
+
+    # ---- extra leg (N = 1): the same timed steps with every closed-form guided call replayed from a hipGraph captured once per
+    # (sigma, part-batch) -- what a server that runs this schedule for batch after batch does (kdip_amd/graphs.py); the CG-branch
+    # calls stay eager.  Captures happen in an untimed pass, sequentially per part.
+    if not args.no_graph_leg and env.world_size == 1 and args.dtype == "bf16":
+        try:
+            from kdip_amd.graphs import GraphedDenoiser
+            for pt in parts:
+                pt["eager_den"], pt["den"] = pt["den"], GraphedDenoiser(pt["den"])
+                with torch.cuda.stream(pt["stream"]):
+                    run_part(pt, sorted(set(idx)), False)                      # capture pass
+                torch.cuda.synchronize()
+            el = timed_run(parts, idx, full_run, 0)
+            rep = sum(pt["den"].replays for pt in parts)
+            eag = sum(pt["den"].eager_calls for pt in parts)
+            out["hipgraph_replay"] = {"ms_per_step": round(el / args.steps * 1e3, 3), "value": round(env.world_size * B / (el / args.steps * 100), 5), "unit": "images/s",
+                                      "graphs": sum(len(pt["den"]._graphs) for pt in parts), "replayed_calls_incl_capture_pass": rep, "eager_calls_cg_branch": eag,
+                                      "note": "same steps and protocol as `value`; closed-form guided calls replayed from hipGraphs (captured in an untimed pass), CG-branch calls eager"}
+            for pt in parts:
+                pt["den"] = pt["eager_den"]
+        except Exception as e:
+            out["hipgraph_replay"] = {"error": repr(e)[:300]}
 
     # ---- extra leg (N = 1, default workload only): the same sampler run at the throughput-optimal batch.  BASELINE configs[1]
     # fixes the batch at 16 images per GPU (that is `value`); per-image cost keeps falling until ~128 images per GPU.  Run as a

@@ -499,3 +499,28 @@ def test_dwtvar_loss_value(tiny, ortho):
         ref.append(float(loss.flatten(1).mean(1)))
     ref = torch.tensor(ref)
     assert float((got - ref).abs().max() / ref.abs().max()) < 2e-4, (got, ref)
+
+
+def test_hipgraph_capture_replay(gold, tiny):
+    """Capture / replay of guided calls (kdip_amd.graphs.GraphedDenoiser): the closed-form branch is captured once per sigma into a
+    hipGraph and replayed for new inputs with results equal to the eager call (fp64-atomic order noise only); the CG branch stays
+    eager (it reads convergence flags back to the host)."""
+    import kdip_amd.condition as kc
+    from kdip_amd.graphs import GraphedDenoiser
+    models, D, sd, cfg = tiny
+    hop, oop, (y, yf), x0 = make_ops("gaussian_blur", gold)
+    den = kc.ConditionOpenAIDenoiser(inner_model=models["f32"], diffusion=D, x0_cov_type="convert", recon_mse=None, operator=hop,
+                                     measurement=(y.cuda(), yf.cuda()), guidance="I", device="cuda")     # (f32 mode: run-to-run noise is ~1e-6;
+    gd = GraphedDenoiser(den)                                                                            #  bf16 re-rounds the atomics-order noise to ~1e-3)
+    g = torch.Generator().manual_seed(21)
+    xs = [(x0 + 1.5 * torch.randn(1, 3, 64, 64, generator=g)).cuda() for _ in range(3)]
+    sig = torch.tensor([1.5], device="cuda")
+    outs = [gd(x, sig) for x in xs]                      # call 0 captures (+ replays), calls 1, 2 replay
+    assert gd.replays == 3 and gd.eager_calls == 0 and len(gd._graphs) == 1
+    for x, o in zip(xs, outs):
+        ref = den(x, sig)
+        assert float((o - ref).abs().max()) < 1e-4
+    assert float((outs[0] - outs[1]).abs().max()) > 1e-3          # different inputs really went through
+    lo = torch.tensor([0.12], device="cuda")                      # CG branch: eager
+    o = gd(xs[0], lo)
+    assert gd.eager_calls == 1 and float((o - den(xs[0], lo)).abs().max()) < 1e-4
