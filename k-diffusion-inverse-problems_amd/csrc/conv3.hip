@@ -210,11 +210,9 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
       unpack16<bf16_t>(o, fd);
       unpack16<bf16_t>(o2, fx);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
+      for (int e = 0; e < 8; ++e) {          // the staged tensor already holds dz = dy * silu'(z) (written by the producing epilogue)
         const float4 k = *(const float4*)(tab + e * C3_PIXB);
-        const float z = k.x * fx[e] + k.y;
-        const float dz = fd[e] * silu_grad_fast(z);
-        fd[e] = k.x * dz - (k.z + k.w * fx[e]);
+        fd[e] = k.x * fd[e] - (k.z + k.w * fx[e]);
       }
       o = pack16<bf16_t>(fd);
     }
@@ -513,8 +511,8 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
             w0y = r[0]; w1y = r[1];
           }
           const uint4 o = make_uint4(w0x, w0y, w1x, w1y);
-          *(uint4*)(yb + mt * rsy + coff + lane_y) = o;
-          if (STM == 2) wst[STM == 2 ? mt : 0][nt][k] = o;
+          if (STM == 2) wst[STM == 2 ? mt : 0][nt][k] = o;        // stored by sweep 2 as dz
+          else *(uint4*)(yb + mt * rsy + coff + lane_y) = o;
         }
         if (STM == 1) {     // quad index nt*4 + 2k (+1) = channels nt*32 + 16k + 4h (+8) .. +3
           ss[nt * 4 + 2 * k] = t1v[0][0] + t1v[0][1]; ss[8 + nt * 4 + 2 * k] = t2v[0][0] + t2v[0][1];
@@ -540,15 +538,20 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
             const uint4 wd = wst[STM == 2 ? mt : 0][nt][k], wx = aux[mt][nt][k];
             const float dy[8] = {bf_lo(wd.x), bf_hi(wd.x), bf_lo(wd.y), bf_hi(wd.y), bf_lo(wd.z), bf_hi(wd.z), bf_lo(wd.w), bf_hi(wd.w)};
             const float xg[8] = {bf_lo(wx.x), bf_hi(wx.x), bf_lo(wx.y), bf_hi(wx.y), bf_lo(wx.z), bf_hi(wx.z), bf_lo(wx.w), bf_hi(wx.w)};
+            float dzv[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
               const float4 kk = ka[e >> 1];
               const float a = (e & 1) ? kk.z : kk.x, b = (e & 1) ? kk.w : kk.y;
               const float z = a * xg[e] + b;
-              const float adz = a * (dy[e] * silu_grad_fast(z));
+              dzv[e] = dy[e] * silu_grad_fast(z);
+              const float adz = a * dzv[e];
               t1[e >> 2] += adz;
               t2[e >> 2] += adz * xg[e];
             }
+            // the tensor this conv leaves in HBM is dz = dy * silu'(z): its consumers (the GroupNorm-backward apply, fused into the
+            // next dgrad conv's staging or run as a pass) then need no transcendental at all
+            *(uint4*)(yb + mt * rsy + (unsigned)((nt * 32 + 16 * k) * 2) + lane_y) = pack16<bf16_t>(dzv);
           }
 #pragma unroll
           for (int q = 0; q < 2; ++q) {

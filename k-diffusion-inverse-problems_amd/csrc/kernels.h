@@ -33,11 +33,12 @@ struct Conv3Fuse {
   int in_ups = 0, res_ups = 0;       // input / residual are half-resolution tensors read at (y >> 1, x >> 1)
   // staging transform of the input patch:
   //   tf 1: A = silu?(a*x + b)                       tf_coef [B][Cin][2] = (a, b)        (gn_coef)
-  //   tf 2: A = a*dz - (k0 + k1*x2), dz = x * silu'?(a*x2 + b)   tf_coef [B][Cin][4] = (a, b, k0, k1)   (gn_bwd_coef); x2 = GroupNorm input
+  //   tf 2: A = a*x - (k0 + k1*x2), x = dz = dy * silu'(z) as a st_mode-2 epilogue stores it   tf_coef [B][Cin][4] = (a, b, k0, k1)   (gn_bwd_coef); x2 = GroupNorm input
   int tf = 0, tf_silu = 0;
   const float* tf_coef = nullptr;
   const void* x2 = nullptr; long ldx2 = 0;
-  // statistics of the OUTPUT accumulated in the epilogue (same meaning as ConvStats::mode 1 / 2)
+  // statistics of the OUTPUT accumulated in the epilogue (same meaning as ConvStats::mode 1 / 2); with st_mode 2 the tensor
+  // written is dz = dy * silu'(a*st_x + b), NOT dy: run the GroupNorm backward of it with silu = 0
   int st_mode = 0, st_silu = 0;
   double* st_sums = nullptr;
   const void* st_x = nullptr; long st_ldx = 0;

@@ -326,6 +326,9 @@ int gn_backward(Ctx& c, const void* x, long ldx, const void* dy, long lddy, cons
 #define KDIP_CONV3 1        // 0: first-generation kernels everywhere (A/B builds)
 #endif
 // true iff this conv runs on the second-generation kernel (bf16, large maps) and can therefore take a fused GroupNorm transform
+#ifndef KDIP_TF2_MAX_COUT
+#define KDIP_TF2_MAX_COUT 256
+#endif
 #ifndef KDIP_CONV3_MIN_BLOCKS
 #define KDIP_CONV3_MIN_BLOCKS 192     // its 256-pixel x 128-channel tiles must at least roughly fill the chip (the 32x32 level does not at batch 8)
 #endif
@@ -336,8 +339,9 @@ bool use_conv3(Ctx& c, const ConvW& w, int B, int H, int W, long ldx, long ldy, 
   if (!conv3_eligible(c.dt, w.ntaps, H, W, cin, cout, ldx, ldy)) return false;
   if ((long)B * (H / 8) * (W / 32) * (cout / 128) < KDIP_CONV3_MIN_BLOCKS) return false;
   if (tf && cin > conv3_tf_max_cin(tf)) return false;
-  // the GroupNorm-backward transform (two tensors, silu') is re-done by every 128-channel output block: fuse it only when there is one
-  if (tf == 2 && cout != 128) return false;
+  // the GroupNorm-backward transform (two tensors, two fmas per element since the producer stores dz) is re-done by every
+  // 128-channel output block
+  if (tf == 2 && cout > KDIP_TF2_MAX_COUT) return false;
   return true;
 }
 
@@ -380,17 +384,19 @@ int conv_f(Ctx& c, const ConvW& w, const void* x, long ldx, int B, int H, int W,
 int conv_b(Ctx& c, const ConvW& w, const void* g, long ldg, int B, int H, int W, void* y, long ldy, const void* res,
            long ldr, int out_f32, const void* gn_x = nullptr, long gn_ldx = 0, const float* gn_coef = nullptr,
            const float* gn_mr = nullptr, int gn_silu = 0, double** sums_out = nullptr, const float* tf2_coef = nullptr,
-           const void* tf2_x2 = nullptr) {
+           const void* tf2_x2 = nullptr, int* y_is_dz = nullptr) {
   bool dry = c.dry;
   if (sums_out) *sums_out = nullptr;
+  if (y_is_dz) *y_is_dz = 0;          // 1: y holds dz = dy * silu'(z) of the GroupNorm (gn_x, gn_coef): apply its backward with silu = 0
   const bool stats_ok = gn_x && sums_out && !out_f32 && ldy == w.cin && conv_stats_eligible(H, W, w.cin) && !gn_small_eligible(c.dt, (long)H * W, w.cin);
-  if (use_conv3(c, w, B, H, W, ldg, ldy, true, out_f32, tf2_coef ? 2 : 0) && !res && (!stats_ok || gn_silu)) {
+  if (use_conv3(c, w, B, H, W, ldg, ldy, true, out_f32, tf2_coef ? 2 : 0) && !res && (!stats_ok || (gn_silu && y_is_dz))) {
     Conv3Fuse fu;
     if (tf2_coef) { fu.tf = 2; fu.tf_silu = 1; fu.tf_coef = tf2_coef; fu.x2 = tf2_x2; fu.ldx2 = ldg; }
     if (stats_ok) {
       fu.st_mode = 2; fu.st_silu = 1; fu.st_x = gn_x; fu.st_ldx = gn_ldx; fu.st_coef = gn_coef; fu.st_mr = gn_mr;
       fu.st_sums = new_sums(c, B);
       *sums_out = fu.st_sums;
+      if (y_is_dz) *y_is_dz = 1;
     }
     RUN(conv3_forward(c.st, g, ldg, B, H, W, w.cin_pad_b, w.wb, nullptr, w.cin, y, ldy, nullptr, 0, &fu, w.cout));
     return KDIP_OK;
@@ -657,12 +663,13 @@ static int res_backward(Ctx& c, Layer& L, const void* G, long ldG, void** gxp, c
   // conv2 dgrad -> grad wrt h3 ; GN2/FiLM/SiLU backward -> grad wrt h2
   void* g3 = u->scratch.alloc(es * B * HWo * L.cout);
   double* sums2 = nullptr;     // GN2-backward sums accumulated by the dgrad epilogue when the shape allows
-  CK(conv_b(c, L.c2, G, ldG, B, Ho, Wo, g3, L.cout, nullptr, 0, 0, L.sv.h2, L.cout, L.sv.coef2, L.sv.mr2, 1, &sums2));
+  int g3_dz = 0;               // g3 holds dz (the dgrad epilogue already applied silu') instead of dy
+  CK(conv_b(c, L.c2, G, ldG, B, Ho, Wo, g3, L.cout, nullptr, 0, 0, L.sv.h2, L.cout, L.sv.coef2, L.sv.mr2, 1, &sums2, nullptr, nullptr, &g3_dz));
   // conv1 dgrad -> grad wrt (resampled) h1.  Second-generation kernel + fused sums: the GN2 backward apply
   // (gh2 = a*dz - (k0 + k1*h2)) happens inside the dgrad conv's input staging; gh2 is never written.
   void* g1p = u->scratch.alloc(es * B * HWo * L.cin);
   double* sums1 = nullptr;
-  const bool fb = sums2 && use_conv3(c, L.c1, B, Ho, Wo, L.cout, L.cin, true, 0, 2);
+  const bool fb = sums2 && g3_dz && use_conv3(c, L.c1, B, Ho, Wo, L.cout, L.cin, true, 0, 2);
   const void* gh2 = nullptr;
   float* tf2 = nullptr;
   if (fb) {
@@ -670,11 +677,12 @@ static int res_backward(Ctx& c, Layer& L, const void* G, long ldG, void** gxp, c
     RUN(gn_bwd_coef(c.st, L.sv.coef2, L.sv.mr2, sums2, B, HWo, L.cout, tf2));
   } else {
     void* t = u->scratch.alloc(es * B * HWo * L.cout);
-    CK(gn_backward(c, L.sv.h2, L.cout, g3, L.cout, L.sv.coef2, L.sv.mr2, B, HWo, L.cout, 1, nullptr, 0, t, L.cout, sums2));
+    CK(gn_backward(c, L.sv.h2, L.cout, g3, L.cout, L.sv.coef2, L.sv.mr2, B, HWo, L.cout, g3_dz ? 0 : 1, nullptr, 0, t, L.cout, sums2));
     gh2 = t;
   }
+  int g1_dz = 0;
   if (L.mode == 0)
-    CK(conv_b(c, L.c1, fb ? g3 : gh2, L.cout, B, Ho, Wo, g1p, L.cin, nullptr, 0, 0, L.sv.x, L.sv.ldx, L.sv.coef1, L.sv.mr1, 1, &sums1, tf2, fb ? L.sv.h2 : nullptr));
+    CK(conv_b(c, L.c1, fb ? g3 : gh2, L.cout, B, Ho, Wo, g1p, L.cin, nullptr, 0, 0, L.sv.x, L.sv.ldx, L.sv.coef1, L.sv.mr1, 1, &sums1, tf2, fb ? L.sv.h2 : nullptr, &g1_dz));
   else
     CK(conv_b(c, L.c1, fb ? g3 : gh2, L.cout, B, Ho, Wo, g1p, L.cin, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, 0, nullptr, tf2, fb ? L.sv.h2 : nullptr));
   // skip path: grad wrt (resampled) x
@@ -702,7 +710,7 @@ static int res_backward(Ctx& c, Layer& L, const void* G, long ldG, void** gxp, c
     g1 = a; gxs = b; ldgxs = L.cin;
   }
   void* gx = u->persist.alloc(es * B * HW * L.cin);
-  CK(gn_backward(c, L.sv.x, L.sv.ldx, g1, L.cin, L.sv.coef1, L.sv.mr1, B, HW, L.cin, 1, gxs, ldgxs, gx, L.cin, sums1, add2, lda2, half_lgW));
+  CK(gn_backward(c, L.sv.x, L.sv.ldx, g1, L.cin, L.sv.coef1, L.sv.mr1, B, HW, L.cin, g1_dz ? 0 : 1, gxs, ldgxs, gx, L.cin, sums1, add2, lda2, half_lgW));
   *gxp = gx;
   return KDIP_OK;
 }
@@ -770,9 +778,10 @@ int UNet::vjp_impl(hipStream_t st, const float* cot_nchw, float* gx_nchw) {
   RUN(nchw_to_nhwc(st, dt, cot_nchw, B, cfg.out_channels, H0, W0, 1.f, cot, 32, 32));
   void* ghn = scratch.alloc(es * B * HW0 * final_ch);
   double* sumsh = nullptr;
-  CK(conv_b(c, out_conv, cot, 32, B, H0, W0, ghn, final_ch, nullptr, 0, 0, final_h, final_ch, out_coef, out_mr, 1, &sumsh));
+  int gh_dz = 0;
+  CK(conv_b(c, out_conv, cot, 32, B, H0, W0, ghn, final_ch, nullptr, 0, 0, final_h, final_ch, out_coef, out_mr, 1, &sumsh, nullptr, nullptr, &gh_dz));
   void* G = persist.alloc(es * B * HW0 * final_ch);
-  CK(gn_backward(c, final_h, final_ch, ghn, final_ch, out_coef, out_mr, B, HW0, final_ch, 1, nullptr, 0, G, final_ch, sumsh));
+  CK(gn_backward(c, final_h, final_ch, ghn, final_ch, out_coef, out_mr, B, HW0, final_ch, gh_dz ? 0 : 1, nullptr, 0, G, final_ch, sumsh));
   const void* g = G; long ldg = final_ch;
   // add2: gradient summed into the block's input gradient by its first layer's last kernel (the concat-skip
   // gradient of the tensor the block consumed) -- replaces a separate add pass per skip connection
