@@ -43,6 +43,9 @@ constexpr int C3_LDS = 2 * C3_ABUF + C3_NSLOT * C3_BSLOT; // 78976 B (+ 64 B dum
 // staging writes or the fragment reads): table slot j = pad of pixel j % 336 of patch buffer j / 336 -> 672 slots.
 // TF 1: slot = 2 channels x (a, b); TF 2: slot = 1 channel x (a, b, k0, k1).
 constexpr int C3_LDS_TOTAL = C3_LDS + 64 + 512;           // + dummy staging slot + statistics exchange [4 waves][2][16] floats
+#ifndef C3_CARRY
+#define C3_CARRY 1             // TF == 0: a stage's k-step-1 MFMAs are issued after the NEXT stage's barrier (explicit software pipeline)
+#endif
 #ifndef C3_BLOCKS_PER_CU
 #define C3_BLOCKS_PER_CU 2
 #endif
@@ -54,6 +57,18 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef C3_ABL_NOATOM
 #define C3_ABL_NOATOM 0        // timing ablations (tools/): statistics atomics off / staging transform math off / no epilogue
+#endif
+#ifndef C3_ABL_NODMA
+#define C3_ABL_NODMA 0         // (K-loop ablations, TF 0 only, results are garbage: no weight DMA / no patch staging / no stage barrier /
+#endif                         //  no fragment reads)
+#ifndef C3_ABL_NOSTG
+#define C3_ABL_NOSTG 0
+#endif
+#ifndef C3_ABL_NOBAR
+#define C3_ABL_NOBAR 0
+#endif
+#ifndef C3_ABL_NOLDSR
+#define C3_ABL_NOLDSR 0
 #endif
 #ifndef C3_ABL_NOTF
 #define C3_ABL_NOTF 0
@@ -127,6 +142,10 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
   int cur = xstart + (blockIdx.x >> 3);
   if (cur >= xend) return;
   C3_STAMP(0);
+#if C3_TIMING
+  if (p.dbg && threadIdx.x == 0 && STM == 0)              // slot 7 (unused without statistics): shader-clock counter at block start
+    p.dbg[(long)blockIdx.x * 8 + 7] = __builtin_readcyclecounter();
+#endif
   const int tpi = p.tilesX * p.tilesY;
   const int Hs = p.in_ups ? p.H >> 1 : p.H, Ws = p.in_ups ? p.W >> 1 : p.W;
   const int nchunks = p.Cin >> 5;
@@ -274,6 +293,10 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
   int pb = 0;                                            // patch buffer that holds chunk 0 of the current tile
   bool first = true;
   uint4 pa[4];                                           // k-step-0 patch fragments of the next stage (carried across stage barriers)
+  // CARRY: the k-step-1 fragments of a stage are consumed after the NEXT stage's barrier, so that the only reads that must wait
+  // for a barrier (the weight fragments of k-step 0) have 8 MFMAs of older work to hide their LDS round trip under
+  constexpr bool CARRY = C3_CARRY && TF == 0;
+  uint4 a1c[4], b1c[2];
 
   for (;;) {
     // ---- current tile
@@ -362,18 +385,18 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
           if (LG) asm volatile("s_waitcnt vmcnt(%5) lgkmcnt(0)" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sa[2]), "+v"(pf0), "+v"(pf1) : "n"(NW) : "memory");
           else asm volatile("s_waitcnt vmcnt(%5)" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sa[2]), "+v"(pf0), "+v"(pf1) : "n"(NW) : "memory");
         }
-        __builtin_amdgcn_s_barrier();
-        {
+        if (!C3_ABL_NOBAR) __builtin_amdgcn_s_barrier();
+        if (!C3_ABL_NODMA) {
           constexpr int t2 = tap + 2 >= 9 ? tap + 2 - 9 : tap + 2;
           if (tap + 2 >= 9) dma_b(wnb, wc, t2, t2 % 3); else dma_b(nb, c, t2, t2 % 3);
         }
-        if (tap >= DIST && tap < DIST + C3_MAXV) {   // (no next tile: the other buffer is dead, the redundant write is harmless and keeps the stage branch free)
+        if (!C3_ABL_NOSTG && tap >= DIST && tap < DIST + C3_MAXV) {   // (no next tile: the other buffer is dead, the redundant write is harmless and keeps the stage branch free)
           constexpr int i = tap >= DIST ? tap - DIST : 0;
           const uint4 o = __builtin_bit_cast(uint4, sa[i % DIST]);
           const uint4 o2 = TF == 2 ? __builtin_bit_cast(uint4, sb[i % DIST]) : make_uint4(0, 0, 0, 0);
           vec_store(nbuf, i, transform(cn, i, o, o2));
         }
-        if (tap < C3_MAXV) vec_load_asm(cn * 64, tap);
+        if (!C3_ABL_NOSTG && tap < C3_MAXV) vec_load_asm(cn * 64, tap);
         if (AUXPF && tap == 6) asm volatile("global_load_dword %0, %1, %2" : "=v"(pf0) : "v"(aux_off), "s"(aux_img) : "memory");
         if (AUXPF && tap == 7) asm volatile("global_load_dword %0, %1, %2 offset:128" : "=v"(pf1) : "v"(aux_off), "s"(aux_img) : "memory");
         // explicit software pipeline of the fragment reads: the k-step-0 patch fragments of stage s+1 are requested under the
@@ -386,6 +409,60 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt) pa[mt] = *(const uint4*)(ab + mt * C3_PW * C3_PIXB + toff);
         }
+        if (CARRY) {
+          // taps 1..8 issue the previous stage's k-step-1 MFMAs first; nothing is carried across a chunk boundary (tap 8 runs its own
+          // k-step 1), where the tile / chunk bookkeeping needs the registers
+          if (C3_ABL_NOLDSR) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+              for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma_bf16(pa[nt], pa[mt], acc[mt][nt]);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+              for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma_bf16(pa[nt + 2], pa[mt], acc[mt][nt]);
+            return;
+          }
+          uint4 b0[2];
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) b0[nt] = *(const uint4*)(bb + nt * 1024);
+          if (tap > 0) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+              for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma_bf16(b1c[nt], a1c[mt], acc[mt][nt]);
+          }
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) a1c[mt] = *(const uint4*)(ab + mt * C3_PW * C3_PIXB + toff + 32);
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) b1c[nt] = *(const uint4*)(bb + (4 + nt) * 1024);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma_bf16(b0[nt], pa[mt], acc[mt][nt]);
+          if (tap < 8) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) pa[mt] = *(const uint4*)(ab + mt * C3_PW * C3_PIXB + toffn);
+          } else {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+              for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma_bf16(b1c[nt], a1c[mt], acc[mt][nt]);
+          }
+          if (C3_SCHED_GROUPS) {
+            if (tap == 0) {
+              __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            } else {
+              __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, tap < 8 ? 8 : 16, 0);
+              if (tap < 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            }
+          }
+        } else {
         uint4 b0[2], b1[2], a1[4];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) b0[nt] = *(const uint4*)(bb + nt * 1024);
@@ -412,6 +489,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
         __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
         if (tap < 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        }
         }
       };
       stage(std::integral_constant<int, 0>{}); stage(std::integral_constant<int, 1>{}); stage(std::integral_constant<int, 2>{});
@@ -610,6 +688,9 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
   // drain the redundant tail loads / DMAs before the wave ends
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   C3_STAMP(6);
+#if C3_TIMING
+  if (p.dbg && threadIdx.x == 0 && STM == 0) p.dbg[(long)blockIdx.x * 8 + 5] = __builtin_readcyclecounter();      // (slot 5: shader clock at block end)
+#endif
 }
 
 template <int TF, int STM, bool RES>

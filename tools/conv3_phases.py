@@ -29,6 +29,13 @@ us = lambda v: v / 100.0
 pro, kl, epi, life = us(t[:, 1] - t[:, 0]), us(t[:, 2] - t[:, 1]), us(t[:, 3] - t[:, 2]), us(t[:, 6] - t[:, 0])
 tpb = ntiles / len(t)
 print(f"persistent blocks {len(t)} ({tpb:.2f} tiles each); launch span {us(t[:, 6].max() - t0):.1f} us; later tiles: {((life - us(t[:, 3] - t[:, 0])) / max(tpb - 1, 1e-9)).mean():.2f} us per tile")
+st, en = us(t[:, 0] - t0), us(t[:, 6] - t0)
+print(f"  block start after first block: p50 {np.percentile(st, 50):.2f} p90 {np.percentile(st, 90):.2f} max {st.max():.2f} us;  block end: p10 {np.percentile(en, 10):.2f} p50 {np.percentile(en, 50):.2f} p90 {np.percentile(en, 90):.2f} max {en.max():.2f} us")
 e1, e2, e3 = us(t[:, 4] - t[:, 2]), us(t[:, 5] - t[:, 4]), us(t[:, 3] - t[:, 5])
 for name, v in (("prologue 1", pro), ("K loop 1", kl), ("epilogue 1", epi), ("  sweep 1 (loads, pack, store)", e1), ("  sweep 2 (bwd stats)", e2), ("  stats combine", e3), ("    of which reduce-scatter", us(np.maximum(t[:, 7] - t[:, 5], 0))), ("block life", life)):
     print(f"  {name:10s} mean {v.mean():7.2f}  p10 {np.percentile(v, 10):7.2f}  p50 {np.percentile(v, 50):7.2f}  p90 {np.percentile(v, 90):7.2f} us")
+
+if stm == 0:      # slots 7 / 5 = shader-clock counter (s_memtime) at block start / end: clock the CUs actually ran at
+    cyc = (t[:, 5] - t[:, 7]).astype(np.float64)
+    ghz = cyc / (life * 1e3)
+    print(f"shader clock during the launch (s_memtime cycles / wall time per block): mean {ghz.mean():.3f} GHz, p10 {np.percentile(ghz, 10):.3f}, p90 {np.percentile(ghz, 90):.3f}")
