@@ -127,6 +127,12 @@ constexpr int KC = 32;            // input channels per B-pipeline stage (one ta
 #ifndef KDIP_SPLITK
 #define KDIP_SPLITK 1
 #endif
+#ifndef KDIP_SPLITK_MINCH
+#define KDIP_SPLITK_MINCH 2    // at least this many K chunks per split
+#endif
+#ifndef KDIP_SPLITK_MAX
+#define KDIP_SPLITK_MAX 16
+#endif
 #ifndef KDIP_SPLITK_FILL
 #define KDIP_SPLITK_FILL 512   // split K until a launch has about this many blocks (2 per CU)
 #endif
@@ -893,8 +899,8 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
     // (3x3 only: on the short-K 1x1 convs the atomics + finalize pass cost more than the extra blocks bring, measured)
     if (KDIP_SPLITK && NTAPS == 9 && p.sk_ws && (long)p.B * p.H * p.W * p.Cout <= p.sk_ws_floats && !p.persist && !p.st_mode && !p.out_f32 && !p.res_ups && p.Cout % 4 == 0 && grid * 2 <= KDIP_SPLITK_FILL && nchunks >= 4) {
       splits = (int)(KDIP_SPLITK_FILL / grid);
-      if (splits > nchunks / 2) splits = nchunks / 2;
-      if (splits > 16) splits = 16;
+      if (splits > nchunks / KDIP_SPLITK_MINCH) splits = nchunks / KDIP_SPLITK_MINCH;
+      if (splits > KDIP_SPLITK_MAX) splits = KDIP_SPLITK_MAX;
     }
   }
   p.sk_splits = splits;

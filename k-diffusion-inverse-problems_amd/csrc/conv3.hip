@@ -46,6 +46,9 @@ constexpr int C3_LDS_TOTAL = C3_LDS + 64 + 512;           // + dummy staging slo
 #ifndef C3_CARRY
 #define C3_CARRY 1             // TF == 0: a stage's k-step-1 MFMAs are issued after the NEXT stage's barrier (explicit software pipeline)
 #endif
+#ifndef C3_KLOOP_PRIO
+#define C3_KLOOP_PRIO 2        // wave priority inside the K loop (epilogue / tile bookkeeping run at 0): the two blocks of a CU share each
+#endif                         // SIMD's VALU issue port, and an older block's epilogue VALU stream otherwise starves the younger block's MFMAs
 #ifndef C3_BLOCKS_PER_CU
 #define C3_BLOCKS_PER_CU 2
 #endif
@@ -347,6 +350,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
       }
     }
 
+    if (C3_KLOOP_PRIO) __builtin_amdgcn_s_setprio(C3_KLOOP_PRIO);
     // Per stage (chunk c, tap t), every wave issues, in this order: 2 weight DMAs (stage s+2), then NV staging loads if t < 6.
     // At the top of stage s the weights of stage s (issued at s-2) and the staging vector written in this stage (issued at
     // s-3) must have landed; still allowed in flight: the staging loads of s-2 and everything of s-1
@@ -497,6 +501,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
       stage(std::integral_constant<int, 6>{}); stage(std::integral_constant<int, 7>{}); stage(std::integral_constant<int, 8>{});
     }
 #undef C3_NVT
+    if (C3_KLOOP_PRIO) __builtin_amdgcn_s_setprio(0);
     pb = (pb + nchunks) & 1;
     if (first) C3_STAMP(2);
 

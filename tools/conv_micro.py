@@ -11,7 +11,16 @@ x = torch.randn(B, Cin, H, W, generator=g).cuda()
 w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * ntaps) ** 0.5).contiguous()
 b = torch.randn(Cout, generator=g)
 y = torch.empty(B, Cout, H, W, device="cuda")
-for _ in range(reps):
-    L.check(lib.kdip_test_conv(L.stream(), 1, ntaps, L.ptr(x), B, Cin, H, W, C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), Cout, 0, L.ptr(y), 1))
-torch.cuda.synchronize()
-print("done", float(y.abs().mean()))
+def run(n):
+    for _ in range(n):
+        L.check(lib.kdip_test_conv(L.stream(), 1, ntaps, L.ptr(x), B, Cin, H, W, C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), Cout, 0, L.ptr(y), 1))
+run(3)
+# the hook allocates / packs per call: time the conv launches themselves with the library's per-launch HIP-event records
+import tempfile, csv
+L.check(lib.kdip_profile_enable(1)); run(reps)
+dump = os.path.join(tempfile.gettempdir(), f"conv_micro_{os.getpid()}.csv")
+L.check(lib.kdip_profile_dump(dump.encode())); L.check(lib.kdip_profile_enable(0))
+rows = [r for r in csv.DictReader(open(dump)) if r["class"].startswith("conv")]
+us = sum(float(r["us"]) for r in rows) / max(len(rows), 1)
+fl = 2.0 * B * H * W * Cin * Cout * ntaps
+print(f"conv B={B} {Cin}->{Cout} @{H}x{W} taps={ntaps} [{rows[0]['class'] if rows else '?'}]: {us:.1f} us/launch ({len(rows)} launches), {fl / us / 1e6:.1f} TFLOP/s, mean |y| {float(y.abs().mean()):.4f}")

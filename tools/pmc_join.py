@@ -56,5 +56,6 @@ for key, c in shapes.items():
     out["shapes"][key] = e
 os.makedirs(os.path.join(ROOT, "profiles", "r02"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "profiles", "r02_pmc_innetwork.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(O, "r02_pmc_innetwork.json"), "w"), indent=1)      # (gpurun merges only gpurun_out/ back: copy this one into profiles/)
 for k, e in sorted(out["shapes"].items(), key=lambda kv: -kv[1]["mean_launch_us_under_pmc"] * kv[1]["launches_per_pass"])[:12]:
     print(k, {a: (round(b, 3) if isinstance(b, float) else b) for a, b in e.items() if a in ("launches_per_pass", "mean_launch_us_under_pmc", "traffic_over_algorithmic", "mfma_busy_frac", "lds_bank_conflict_frac_of_lds_active", "l2_hit_rate", "shader_clock_ghz")})
