@@ -63,6 +63,8 @@ int kdip_unet_forward(kdip_unet* u, void* stream, const float* x_dev, const floa
  * gx_dev [B,in_ch,S,S] fp32; B must equal the batch of that forward (KDIP_ERR_ARG otherwise).  May be called repeatedly. */
 int kdip_unet_vjp(kdip_unet* u, void* stream, const float* cot_dev, int B, float* gx_dev);
 /* bytes of device workspace currently held for batch B (allocated lazily, grows monotonically). */
+/* Debug / test aid: 64-bit word sum of the activation stash kdip_unet_vjp reads (unchanged between a forward and its VJPs). */
+int kdip_unet_debug_stash_checksum(kdip_unet* u, void* stream, unsigned long long* sum_host);
 long kdip_unet_workspace_bytes(kdip_unet* u, int B);
 
 /* ------------------------------------------------- operators / solvers (rows A9-A13)
@@ -180,6 +182,11 @@ int kdip_lpips_layer(void* stream, const float* f0_dev, const float* f1_dev, con
 int kdip_test_conv(void* stream, int dtype, int ntaps, const float* x_nchw_dev, int B, int Cin, int H, int W,
                    const float* w_host, const float* bias_host, int Cout, int transpose_flip, float* y_nchw_dev,
                    int storage_out /* 0: fp32 NHWC epilogue (output heads); 1: storage-dtype epilogue (UNet-internal) */);
+/* Test hook of the fused attention forward + VJP (replaces QKVAttentionLegacy.forward, guided_diffusion/unet.py:339-356, and its
+ * autograd backward): device fp32 qkv [B][T][3C] (C = 64 * heads, head h at channels 192 h + q | k | v), dO [B][T][C]; inputs are
+ * rounded to bf16; outputs o [B][T][C], dqkv [B][T][3C] as fp32.  T must be a multiple of 64. */
+int kdip_test_attention(void* stream, const float* qkv_dev, const float* dO_dev, int B, int T, int heads, float* o_dev, float* dqkv_dev);
+
 /* Second-generation bf16 3x3 conv (csrc/conv3.hip) with its fused GroupNorm staging transforms and epilogue statistics.
  * Tensor arguments are device fp32 NCHW; tf 1: tf_coef [B][Cin][2] = (a, b); tf 2: x = dy, x2 = GroupNorm input,
  * tf_coef [B][Cin][4] = (a, b, k0, k1); st_mode 1 / 2: sums_dev [B][32][2] (fp64) receives the GroupNorm forward / backward

@@ -21,6 +21,7 @@ SIGNATURES = {
     "kdip_unet_finalize": (C.c_int, [VP]),
     "kdip_unet_forward": (C.c_int, [VP, VP, VP, VP, C.c_int, C.c_float, VP, VP, VP]),
     "kdip_unet_vjp": (C.c_int, [VP, VP, VP, C.c_int, VP]),
+    "kdip_unet_debug_stash_checksum": (C.c_int, [VP, VP, VP]),
     "kdip_unet_workspace_bytes": (C.c_long, [VP, C.c_int]),
     "kdip_op_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(VP)]),
     "kdip_op_destroy": (None, [VP]),
@@ -65,6 +66,7 @@ SIGNATURES = {
     "kdip_debug_conv_timing": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, C.c_int]),
     "kdip_test_conv": (C.c_int, [VP, C.c_int, C.c_int, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, C.c_int, C.c_int, VP, C.c_int]),
     "kdip_debug_conv3_timing": (C.c_int, [VP]),
+    "kdip_test_attention": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_int, VP, VP]),
     "kdip_test_conv3": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, C.c_int, C.c_int, C.c_int, VP, VP, C.c_int, C.c_int,
                                   C.c_int, VP, VP, VP, VP, VP, C.c_int, VP]),
     "kdip_test_groupnorm": (C.c_int, [VP, C.c_int, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, VP, C.c_int, VP, VP, VP]),

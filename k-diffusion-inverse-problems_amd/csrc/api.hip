@@ -62,6 +62,30 @@ int kdip_unet_vjp(kdip_unet* u, void* stream, const float* cot_dev, int B, float
   KDIP_HIP_CHECK(hipSetDevice(u->u.device));
   return u->u.vjp(ST(stream), cot_dev, gx_dev);
 }
+namespace {
+__global__ void checksum_kernel(const unsigned* __restrict__ w, size_t n, unsigned long long* out) {
+  unsigned long long s = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) s += w[i];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+}  // namespace
+// Debug / test aid: word sum of the activation stash the VJP reads (persist arena up to the end of the last forward).  Tests use it
+// to assert that nothing between unet_forward and unet_vjp (solver, operators, host code) writes into the handle's workspace.
+int kdip_unet_debug_stash_checksum(kdip_unet* u, void* stream, unsigned long long* sum_host) {
+  KDIP_REQUIRE(u && sum_host, "null argument");
+  KDIP_REQUIRE(u->u.have_stash, "no forward stash");
+  KDIP_HIP_CHECK(hipSetDevice(u->u.device));
+  unsigned long long* d = nullptr;
+  KDIP_HIP_CHECK(hipMalloc((void**)&d, 8));
+  KDIP_HIP_CHECK(hipMemsetAsync(d, 0, 8, ST(stream)));
+  const size_t n = u->u.persist.off / 4;
+  hipLaunchKernelGGL(checksum_kernel, dim3(2048), dim3(256), 0, ST(stream), (const unsigned*)u->u.persist.base, n, d);
+  KDIP_HIP_CHECK(hipMemcpyAsync(sum_host, d, 8, hipMemcpyDeviceToHost, ST(stream)));
+  KDIP_HIP_CHECK(hipStreamSynchronize(ST(stream)));
+  (void)hipFree(d);
+  return KDIP_OK;
+}
 long kdip_unet_workspace_bytes(kdip_unet* u, int B) {
   if (!u) return -1;
   if (B > 0 && u->u.finalized) { int rc = u->u.ensure_workspace(B); if (rc) return rc; }
@@ -274,6 +298,29 @@ int kdip_gauss_nll_mean(void* stream, const float* pred, const float* target, co
 int kdip_relu_maxpool(void* stream, const float* x, long planes, int H, int W, int pool, float* y) { return relu_maxpool_planes(ST(stream), x, planes, H, W, pool, y); }
 int kdip_lpips_layer(void* stream, const float* f0, const float* f1, const float* lin_w, int B, int C, long HW, float* out_accum) {
   return lpips_layer(ST(stream), f0, f1, lin_w, B, C, HW, out_accum);
+}
+
+// Test hook of the fused attention (csrc/attention.hip): device fp32 qkv [B][T][3C] (head h at channels 192 h + q|k|v) and output
+// cotangent dO [B][T][C] are rounded to bf16, forward + VJP run, results come back as fp32 (o [B][T][C], dqkv [B][T][3C]).
+int kdip_test_attention(void* stream, const float* qkv_dev, const float* dO_dev, int B, int T, int heads, float* o_dev, float* dqkv_dev) {
+  hipStream_t st = ST(stream);
+  const int C = heads * 64;
+  const size_t nq = (size_t)B * T * 3 * C, no = (size_t)B * T * C;
+  void *qkv = nullptr, *dO = nullptr, *o = nullptr, *dq = nullptr, *ws = nullptr; float *lse = nullptr, *D = nullptr;
+  KDIP_HIP_CHECK(hipMalloc(&qkv, 2 * nq)); KDIP_HIP_CHECK(hipMalloc(&dO, 2 * no)); KDIP_HIP_CHECK(hipMalloc(&o, 2 * no));
+  KDIP_HIP_CHECK(hipMalloc(&dq, 2 * nq)); KDIP_HIP_CHECK(hipMalloc(&ws, 2 * no * 3));
+  KDIP_HIP_CHECK(hipMalloc((void**)&lse, sizeof(float) * B * heads * T)); KDIP_HIP_CHECK(hipMalloc((void**)&D, sizeof(float) * B * heads * T));
+  int rc = f32_to_bf16(st, qkv_dev, (long)nq, qkv);
+  if (!rc) rc = f32_to_bf16(st, dO_dev, (long)no, dO);
+  if (!rc) rc = attn_fused_forward(st, qkv, 3 * C, B, T, heads, ws, o, C, lse);
+  if (!rc) rc = attn_fused_backward(st, qkv, 3 * C, dO, C, o, C, lse, B, T, heads, ws, D, dq, 3 * C);
+  if (!rc) rc = T_to_f32(st, DT_BF16, o, (long)no, o_dev);
+  if (!rc) rc = T_to_f32(st, DT_BF16, dq, (long)nq, dqkv_dev);
+  hipError_t e = hipStreamSynchronize(st);
+  (void)hipFree(qkv); (void)hipFree(dO); (void)hipFree(o); (void)hipFree(dq); (void)hipFree(ws); (void)hipFree(lse); (void)hipFree(D);
+  if (rc) return rc;
+  KDIP_HIP_CHECK(e);
+  return KDIP_OK;
 }
 
 // conv3.hip through the C ABI: every tensor argument is a device fp32 NCHW tensor (converted to the bf16 NHWC storage

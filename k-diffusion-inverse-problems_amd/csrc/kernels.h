@@ -63,6 +63,14 @@ struct BGemm {
 };
 int bgemm(hipStream_t st, DType dt, const BGemm& g);
 
+// ---- attention.hip: fused QKVAttentionLegacy forward / VJP (bf16, head width 64, T % 64 == 0); qkv [B][T][ld] with head h at
+// channels 192 h + (q | k | v), output / cotangent [B][T][ld*] with head h at channels 64 h
+bool attn_fused_eligible(DType dt, int T, int head_channels, long ld_qkv);
+int f32_to_bf16(hipStream_t st, const float* x, long n, void* y);      // (test hook helper)
+int attn_fused_forward(hipStream_t st, const void* qkv, long ld, int B, int T, int heads, void* vt_ws, void* o, long ldo, float* lse);
+int attn_fused_backward(hipStream_t st, const void* qkv, long ld, const void* dO, long lddo, const void* o, long ldo, const float* lse,
+                        int B, int T, int heads, void* ws, float* D, void* dqkv, long ldg);
+
 // ---- norm.hip ---------------------------------------------------------------------------
 // GroupNorm(32) over NHWC [B, HW, C] (ld = channel stride). stats: double [B][32][2] (sum, sumsq), zeroed by callee.
 int gn_stats(hipStream_t st, DType dt, const void* x, long ldx, int B, long HW, int C, double* stats, int prezeroed = 0);

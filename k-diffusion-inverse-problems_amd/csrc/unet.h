@@ -30,6 +30,7 @@ struct Saved {            // per-layer stash for the VJP
   void* h2 = nullptr;
   float *coef1 = nullptr, *mr1 = nullptr, *coef2 = nullptr, *mr2 = nullptr;
   void* qkv = nullptr; void* P = nullptr;
+  void* ao = nullptr; float* lse = nullptr;      // fused attention: saved attention output and per-row log-sum-exp (instead of P)
   int B = 0, H = 0, W = 0;
 };
 

@@ -504,6 +504,9 @@ static int res_forward(Ctx& c, Layer& L, const void* x, long ldx, int B, int& H,
   return KDIP_OK;
 }
 
+#ifndef KDIP_FUSED_ATTN
+#define KDIP_FUSED_ATTN 1     // bf16, head width 64, T % 64 == 0: csrc/attention.hip (0: the bgemm + softmax passes)
+#endif
 static void attn_gemms(const Layer& L, int B, int T, int hc, BGemm& qk, BGemm& pv, const void* qkv, void* S, const void* P, void* a) {
   const int C = L.cin, heads = L.heads;
   const size_t dummy = 0; (void)dummy;
@@ -532,10 +535,19 @@ static int attn_forward(Ctx& c, Layer& L, const void* x, long ldx, int B, int H,
   void* qkv = u->persist.alloc(es * (size_t)B * T * 3 * C);
   L.sv.qkv = qkv;
   CK(conv_f(c, L.qkv, n, C, B, H, W, qkv, 3 * C, nullptr, 0, 0));
+  void* a;
+  if (KDIP_FUSED_ATTN && attn_fused_eligible(c.dt, T, hc, 3 * C)) {
+    // scores never reach HBM; the VJP recomputes the probabilities from the saved output + log-sum-exp
+    a = u->persist.alloc(es * (size_t)B * T * C);
+    float* lse = (float*)u->persist.alloc(sizeof(float) * (size_t)B * heads * T);
+    void* vt = u->scratch.alloc(es * (size_t)B * T * C);
+    L.sv.ao = a; L.sv.lse = lse; L.sv.P = nullptr;
+    RUN(attn_fused_forward(c.st, qkv, 3 * C, B, T, heads, vt, a, C, lse));
+  } else {
   float* S = (float*)u->scratch.alloc(sizeof(float) * (size_t)B * heads * T * T);
   void* P = u->persist.alloc(es * (size_t)B * heads * T * T);
-  L.sv.P = P;
-  void* a = u->scratch.alloc(es * (size_t)B * T * C);
+  L.sv.P = P; L.sv.ao = nullptr;
+  a = u->scratch.alloc(es * (size_t)B * T * C);
   BGemm qk, pv;
   attn_gemms(L, B, T, hc, qk, pv, qkv, S, P, a);
   qk.Bm = (const char*)qkv + es * hc;
@@ -543,6 +555,7 @@ static int attn_forward(Ctx& c, Layer& L, const void* x, long ldx, int B, int H,
   RUN(bgemm(c.st, c.dt, qk));
   RUN(softmax_rows(c.st, c.dt, S, (long)B * heads * T, T, P));
   RUN(bgemm(c.st, c.dt, pv));
+  }
   void* o = dst ? dst : u->persist.alloc(es * (size_t)B * T * C);
   CK(conv_f(c, L.proj, a, C, B, H, W, o, dst ? ldd : C, x, ldx, 0, true));
   *outp = o;
@@ -723,10 +736,15 @@ static int attn_backward(Ctx& c, Layer& L, const void* G, long ldG, void** gxp, 
   const int B = L.sv.B, H = L.sv.H, W = L.sv.W, C = L.cin, T = H * W, hc = u->cfg.num_head_channels, heads = L.heads;
   void* ga = u->scratch.alloc(es * (size_t)B * T * C);
   CK(conv_b(c, L.proj, G, ldG, B, H, W, ga, C, nullptr, 0, 0));
-  float* dP = (float*)u->scratch.alloc(sizeof(float) * (size_t)B * heads * T * T);
-  void* dS = u->scratch.alloc(es * (size_t)B * heads * T * T);
   void* dqkv = u->scratch.alloc(es * (size_t)B * T * 3 * C);
   const char* qkv = (const char*)L.sv.qkv;
+  if (KDIP_FUSED_ATTN && attn_fused_eligible(c.dt, T, hc, 3 * C)) {
+    void* ws = u->scratch.alloc(es * (size_t)B * T * C * 3);
+    float* D = (float*)u->scratch.alloc(sizeof(float) * (size_t)B * heads * T);
+    RUN(attn_fused_backward(c.st, qkv, 3 * C, ga, C, L.sv.ao, C, L.sv.lse, B, T, heads, ws, D, dqkv, 3 * C));
+  } else {
+  float* dP = (float*)u->scratch.alloc(sizeof(float) * (size_t)B * heads * T * T);
+  void* dS = u->scratch.alloc(es * (size_t)B * heads * T * T);
   const float alpha = 1.f / sqrtf((float)hc);
   BGemm g;
   // dP[t][s] = sum_d ga[t][d] V[s][d]
@@ -754,6 +772,7 @@ static int attn_backward(Ctx& c, Layer& L, const void* G, long ldG, void** gxp, 
   g.C = (char*)dqkv + es * hc; g.scm = 3 * C; g.scn = 1; g.scb1 = (long)T * 3 * C; g.scb2 = 3 * hc;
   g.M = T; g.N = hc; g.K = T; g.nb1 = B; g.nb2 = heads; g.alpha = alpha; g.c_f32 = 0;
   RUN(bgemm(c.st, c.dt, g));
+  }
   void* gn_in = u->scratch.alloc(es * (size_t)B * T * C);
   double* sumsn = nullptr;
   CK(conv_b(c, L.qkv, dqkv, 3 * C, B, H, W, gn_in, C, nullptr, 0, 0, L.sv.x, L.sv.ldx, L.sv.coef1, L.sv.mr1, 0, &sumsn));

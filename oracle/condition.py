@@ -41,6 +41,10 @@ class GuidedDenoiser:
         self.v2 = v2
         self.D = tables or DiffusionTables()
         self.cg_stats = {}
+        # test aid: gradient mask of the x0 clamp imposed by the caller (bool tensor) -- for pixels whose |x0_raw| equals 1 to
+        # within rounding either side of the mask is a correct answer, and the two differ by O(1) in the guided output
+        self.clamp_mask_override = None
+        self.last_x0_raw = None
 
     # ------------------------------------------------------------- uncond ----
     def uncond_pred(self, x, sigma):
@@ -59,8 +63,12 @@ class GuidedDenoiser:
         max_log = _bc(D.f32(D.log_betas, t), x)
         frac = (v + 1) / 2
         variance = torch.exp(frac * max_log + (1 - frac) * min_log)                       # :270-276
-        x0_mean = (_bc(D.f32(D.sqrt_recip_alphas_cumprod, t), x) * x_in
-                   - _bc(D.f32(D.sqrt_recipm1_alphas_cumprod, t), x) * eps).clamp(-1, 1)   # :293-311,328-333
+        x0_raw = (_bc(D.f32(D.sqrt_recip_alphas_cumprod, t), x) * x_in
+                  - _bc(D.f32(D.sqrt_recipm1_alphas_cumprod, t), x) * eps)
+        self.last_x0_raw = x0_raw.detach()
+        x0_mean = x0_raw.clamp(-1, 1)                                                      # :293-311,328-333
+        if self.clamp_mask_override is not None:
+            x0_mean = torch.where(self.clamp_mask_override, x0_raw, x0_mean.detach())
         ct = self.x0_cov_type
         base = s0.pow(2) / (1 + s0.pow(2))
         if ct == "convert":

@@ -91,14 +91,24 @@ def test_imagenet_motion_typeI_analytic_fullsize(sigma_v):
     from helpers import synthetic_recon_mse
     m, sd, ocfg, hop, oop, meas, x0 = _setup("IMAGENET", "motion_blur", "f32", B=2)
     rm = synthetic_recon_mse()
-    x = x0 + sigma_v * torch.randn(2, 3, 256, 256, generator=torch.Generator().manual_seed(11))
-    ref = ocond.GuidedDenoiser(sd, ocfg, oop, meas, "I", x0_cov_type="analytic", recon_mse=rm)(x, torch.full((2,), sigma_v))
     D = ku.GaussianDiffusionTables()
     measd = (meas[0].cuda(), meas[1].cuda())
     rmd = {k: v.cuda() for k, v in rm.items()}
     hm = kc.ConditionOpenAIDenoiser(inner_model=m, diffusion=D, x0_cov_type="analytic", recon_mse=rmd, operator=hop,
                                     measurement=measd, guidance="I", device="cuda")
+    # The guided output is DISCONTINUOUS in the UNet output where |x0_raw| crosses 1: the VJP goes through clamp(-1, 1)
+    # (condition.py:231 `pred_xstart.clamp`), whose gradient mask flips.  With this input one pixel of image 0 has
+    # x0_raw = -1 +- 2e-6, inside the run-to-run noise of the fp32 split-K atomics: either side of the mask is then a correct
+    # answer and the two differ by O(1) over that pixel's receptive field.  The oracle is therefore run with the HIP path's
+    # mask; the test asserts that the two masks only disagree at such borderline pixels.
+    x = x0 + sigma_v * torch.randn(2, 3, 256, 256, generator=torch.Generator().manual_seed(11))
     hat = hm(x.cuda(), torch.full((2,), sigma_v, device="cuda")).cpu()
+    hip_raw = hm._stash[0].cpu()
+    oden = ocond.GuidedDenoiser(sd, ocfg, oop, meas, "I", x0_cov_type="analytic", recon_mse=rm)
+    oden.clamp_mask_override = hip_raw.abs() <= 1
+    ref = oden(x, torch.full((2,), sigma_v))
+    flips = (oden.last_x0_raw.abs() <= 1) != oden.clamp_mask_override
+    assert int(flips.sum()) <= 4 and (not flips.any() or float((oden.last_x0_raw[flips].abs() - 1).abs().max()) < 1e-4)
     err = float((hat - ref).abs().max())
     del m, hm
     torch.cuda.empty_cache()
@@ -107,7 +117,7 @@ def test_imagenet_motion_typeI_analytic_fullsize(sigma_v):
                                      measurement=measd, guidance="I", device="cuda")
     hat2 = hm2(x.cuda(), torch.full((2,), sigma_v, device="cuda")).cpu()
     p = psnr_db(hat2, ref)
-    print(f"\nconfigs[3] ImageNet motion Type-I analytic sigma={sigma_v} B=2: f32 max-abs {err:.2e}; bf16 PSNR(hip, oracle) {p:.1f} dB, "
+    print(f"\nconfigs[3] ImageNet motion Type-I analytic sigma={sigma_v} B=2 ({int(flips.sum())} borderline clamp pixels): f32 max-abs {err:.2e}; bf16 PSNR(hip, oracle) {p:.1f} dB, "
           f"bf16 max-abs {float((hat2 - ref).abs().max()):.2e}")
     assert err < 2e-3, err
     assert torch.isfinite(hat2).all() and p > 25.0      # measured 30.0 dB (sigma 1.5: clamp flips on saturated random-weight outputs) / 66.1 dB (sigma 0.12)

@@ -12,4 +12,4 @@ run b "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_I
 run c "FETCH_SIZE"
 run d "WRITE_SIZE"
 run e "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"
-cd $R && python tools/pmc_join.py
+cd $R && python tools/pmc_join.py   # (also writes gpurun_out/pmcnet/r02_pmc_innetwork.json, which gpurun merges back)
