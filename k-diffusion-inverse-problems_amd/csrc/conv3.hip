@@ -556,15 +556,14 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
     float ss[16];                                           // [0..7]: sum 1 per channel quad, [8..15]: sum 2
 #pragma unroll
     for (int i = 0; i < 16; ++i) ss[i] = 0.f;
-    // ---- sweep 1: (residual,) pack, forward statistics, store
+    // ---- sweep 1: (residual,) pack, forward statistics, store.  Pixel row outermost: the four 16-byte vectors of a pixel (this
+    // wave's 64 channels = one 128-byte run) are stored back to back so that L2 merges them into whole lines before they leave
+    // for HBM (channel-vector-major order wrote 1.14 - 1.27 x the tensor: WRITE_SIZE of the in-network launches).
+    f32x2 t1v[2][2][2], t2v[2][2][2];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const unsigned coff = (unsigned)((nt * 32 + 16 * k) * 2);
-        f32x2 t1v[2] = {{0.f, 0.f}, {0.f, 0.f}}, t2v[2] = {{0.f, 0.f}, {0.f, 0.f}};
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+    for (int i = 0; i < 8; ++i) { (&t1v[0][0][0])[i] = (f32x2){0.f, 0.f}; (&t2v[0][0][0])[i] = (f32x2){0.f, 0.f}; }
+    auto emit = [&](int mt, int nt, int k) {
+          const unsigned coff = (unsigned)((nt * 32 + 16 * k) * 2);
           float v[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = acc[mt][nt][8 * k + e];
@@ -580,10 +579,10 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
           uint32_t w0x = pack_bf16x2(v[0], v[1]), w0y = pack_bf16x2(v[2], v[3]);
           uint32_t w1x = pack_bf16x2(v[4], v[5]), w1y = pack_bf16x2(v[6], v[7]);
           if (STM == 1) {     // statistics of the fp32 values (before the bf16 rounding of the store), two lanes of packed fp32 math
-            t1v[0] += (f32x2){v[0], v[1]}; t1v[0] += (f32x2){v[2], v[3]};
-            t2v[0] += (f32x2){v[0], v[1]} * (f32x2){v[0], v[1]}; t2v[0] += (f32x2){v[2], v[3]} * (f32x2){v[2], v[3]};
-            t1v[1] += (f32x2){v[4], v[5]}; t1v[1] += (f32x2){v[6], v[7]};
-            t2v[1] += (f32x2){v[4], v[5]} * (f32x2){v[4], v[5]}; t2v[1] += (f32x2){v[6], v[7]} * (f32x2){v[6], v[7]};
+            t1v[nt][k][0] += (f32x2){v[0], v[1]}; t1v[nt][k][0] += (f32x2){v[2], v[3]};
+            t2v[nt][k][0] += (f32x2){v[0], v[1]} * (f32x2){v[0], v[1]}; t2v[nt][k][0] += (f32x2){v[2], v[3]} * (f32x2){v[2], v[3]};
+            t1v[nt][k][1] += (f32x2){v[4], v[5]}; t1v[nt][k][1] += (f32x2){v[6], v[7]};
+            t2v[nt][k][1] += (f32x2){v[4], v[5]} * (f32x2){v[4], v[5]}; t2v[nt][k][1] += (f32x2){v[6], v[7]} * (f32x2){v[6], v[7]};
           }
           // lanes l and l + 32 hold the same pixel: after the swaps lanes < 32 own channels 16k .. 16k+7 and lanes >= 32
           // own 16k+8 .. 16k+15 of their n-tile -> one 16-byte store each
@@ -594,14 +593,35 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
             w0y = r[0]; w1y = r[1];
           }
           const uint4 o = make_uint4(w0x, w0y, w1x, w1y);
-          if (STM == 2) wst[STM == 2 ? mt : 0][nt][k] = o;        // stored by sweep 2 as dz
+          if (STM == 2) wst[STM == 2 ? mt : 0][nt][k] = o;        // turned into dz and stored by sweep 2
           else *(uint4*)(yb + mt * rsy + coff + lane_y) = o;
+    };
+    // Order of the 16 (pixel row, channel vector) items.  Row-major is what the memory system wants (above); without a residual
+    // it costs 11 - 20 spilled registers in this region and measures 3 - 5 % slower, so those variants keep vector-major order.
+    constexpr bool ROW_MAJOR = RES || STM == 2;
+    if (ROW_MAJOR) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int k = 0; k < 2; ++k) emit(mt, nt, k);
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) emit(mt, nt, k);
+    }
+    if (STM == 1) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {     // quad index nt*4 + 2k (+1) = channels nt*32 + 16k + 4h (+8) .. +3
+          ss[nt * 4 + 2 * k] = t1v[nt][k][0][0] + t1v[nt][k][0][1]; ss[8 + nt * 4 + 2 * k] = t2v[nt][k][0][0] + t2v[nt][k][0][1];
+          ss[nt * 4 + 2 * k + 1] = t1v[nt][k][1][0] + t1v[nt][k][1][1]; ss[8 + nt * 4 + 2 * k + 1] = t2v[nt][k][1][0] + t2v[nt][k][1][1];
         }
-        if (STM == 1) {     // quad index nt*4 + 2k (+1) = channels nt*32 + 16k + 4h (+8) .. +3
-          ss[nt * 4 + 2 * k] = t1v[0][0] + t1v[0][1]; ss[8 + nt * 4 + 2 * k] = t2v[0][0] + t2v[0][1];
-          ss[nt * 4 + 2 * k + 1] = t1v[1][0] + t1v[1][1]; ss[8 + nt * 4 + 2 * k + 1] = t2v[1][0] + t2v[1][1];
-        }
-      }
     }
     if (first) C3_STAMP(4);
     // ---- sweep 2 (backward statistics), in the STORE layout: this lane's vector (nt, k) = channels nt*32 + 16k + 8h .. +7 of
@@ -634,7 +654,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
             }
             // the tensor this conv leaves in HBM is dz = dy * silu'(z): its consumers (the GroupNorm-backward apply, fused into the
             // next dgrad conv's staging or run as a pass) then need no transcendental at all
-            *(uint4*)(yb + mt * rsy + (unsigned)((nt * 32 + 16 * k) * 2) + lane_y) = pack16<bf16_t>(dzv);
+            wst[STM == 2 ? mt : 0][nt][k] = pack16<bf16_t>(dzv);          // (in place: stored below, a pixel's 128 bytes together)
           }
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
@@ -644,6 +664,18 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
           }
         }
       }
+    }
+    if (STM == 2) {
+      // stores of the whole tile, pixel row by pixel row: the four 16-byte vectors of a pixel (channels 0..63 of this wave = one
+      // 128-byte run) back to back, so L2 merges them into whole lines.  Issued from inside the (nt, k) loop above, the pieces of
+      // a line were written a long stretch of VALU work apart and reached HBM as partial lines (WRITE_SIZE = 2 x the tensor).
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+            *(uint4*)(yb + mt * rsy + (unsigned)((nt * 32 + 16 * k) * 2) + lane_y) = wst[STM == 2 ? mt : 0][nt][k];
     }
     if (first) C3_STAMP(5);
     if (STM) {
