@@ -278,6 +278,14 @@ def main():
             "launches": cnt, "avg_launch_us": round(us / cnt, 2), "algorithmic_gflop_per_launch": round(gf / cnt, 3),
             "algorithmic_bytes_per_launch": round(mb / cnt * 1e6),
             "share_of_profiled_conv_time": round(us / max(sum(v[1] for v in grp.values()), 1e-9), 3),
+            # `peak` is the nominal dense bf16 figure (2.4 GHz); the chip sustains 1.8 - 2.1 GHz under these launches (GRBM_GUI_ACTIVE /
+            # duration in pmc_in_network; s_memtime / wall clock in tools/conv3_phases.py: 1.78 GHz), so the same launch also as a
+            # fraction of the MFMA rate at the clock it actually ran at
+            "frac_of_peak_at_measured_clock": (round(tflops / (BF16_MFMA_PEAK_TFLOPS * pmc_extra["shader_clock_ghz"] / 2.4), 4)
+                                               if pmc_extra.get("shader_clock_ghz") else None),
+            "top_conv_launch_groups": [{"tag": kk[1], "B": int(kk[2]), "HW": int(kk[3]), "Cin": int(kk[4]), "Cout": int(kk[5]), "launches": vv[0],
+                                        "avg_launch_us": round(vv[1] / vv[0], 1), "tflops": round(vv[2] / vv[1] * 1e3, 1)}
+                                       for kk, vv in sorted(grp.items(), key=lambda kv: -kv[1][1])[:8]],
             "class_aggregate": {"kernel_class": lib.kdip_profile_class_name(k).decode(), "tflops": round(fl[k] / max(ms[k], 1e-9) / 1e9, 2),
                                 "launches": int(la[k]), "avg_launch_us": round(ms[k] * 1e3 / max(la[k], 1), 2)},
             "all_conv_classes": {lib.kdip_profile_class_name(j).decode(): {"ms": round(ms[j], 3), "tflops": round(fl[j] / max(ms[j], 1e-9) / 1e9, 2), "launches": int(la[j])}
