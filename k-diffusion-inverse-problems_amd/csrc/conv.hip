@@ -95,6 +95,9 @@ int conv_debug_timing(void* buf, int H, int cin, int cout, int st_mode) {
 #endif
 
 constexpr int KC = 32;            // input channels per B-pipeline stage (one tap of one 32-channel sub-chunk)
+#ifndef KDIP_B_DEPTH_SMALL
+#define KDIP_B_DEPTH_SMALL 2      // B-fragment stages in flight for the one- / two-MFMA-tile-per-wave configurations (small-map layers);
+#endif                           // 4 and 6 measured the same 19 - 32 us per launch as 2: not bound by the weight stream latency
 #ifndef KDIP_B_DEPTH
 #define KDIP_B_DEPTH 2
 #endif
@@ -485,13 +488,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) dst[ks][nt] = *bptr(tp, (long)c32 * KS + ks, nt);
   };
-  uint4 bq0[KS][NT], bq1[KS][NT], bq2[KS][NT];
+  constexpr int BD = (MT * NT <= 2 && sizeof(T) == 2 && NTAPS == 9) ? KDIP_B_DEPTH_SMALL : KDIP_B_DEPTH;   // stages ahead
+  uint4 bq[BD + 1][KS][NT];
 
   // prologue: the first two B stages are requested together with the first patch, ahead of the LDS write + barrier
   // (issued after the barrier their L2 latency sat exposed in front of the first MFMA)
   if (!have_patch) stage_load(c_begin);
-  load_b(bq0, c_begin * SUBS * NTAPS);
-  if (KDIP_B_DEPTH == 2) load_b(bq1, c_begin * SUBS * NTAPS + 1);
+#pragma unroll
+  for (int i = 0; i < BD; ++i) load_b(bq[i], c_begin * SUBS * NTAPS + i);
   if (!have_patch) {
     stage_write(pb);
     __syncthreads();
@@ -533,7 +537,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
     for (int sub = 0; sub < SUBS; ++sub) {
 #pragma unroll
       for (int tap = 0; tap < NTAPS; ++tap) {
-        if (!KDIP_ABL_NOB) load_b(bq2, (c * SUBS + sub) * NTAPS + tap + KDIP_B_DEPTH);
+        if (!KDIP_ABL_NOB) load_b(bq[BD], (c * SUBS + sub) * NTAPS + tap + BD);
         {
           int ntap = tap + 1, nsub = sub;
           if (ntap == NTAPS) { ntap = 0; nsub = sub + 1; }
@@ -545,7 +549,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) Mma<T>::run(aq0[ks][mt], bq0[ks][nt], acc[mt][nt]);
+            for (int nt = 0; nt < NT; ++nt) Mma<T>::run(aq0[ks][mt], bq[0][ks][nt], acc[mt][nt]);
         if (KDIP_SETPRIO) __builtin_amdgcn_s_setprio(0);
         if (!KDIP_ABL_NOSTAGE && NTAPS * SUBS > 1 && sub == 0 && tap == 0) next_load(c);
         // the other LDS buffer was last read in chunk c-1 (all waves are past that barrier), so the next
@@ -555,8 +559,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
-            if (KDIP_B_DEPTH == 2) { bq0[ks][nt] = bq1[ks][nt]; bq1[ks][nt] = bq2[ks][nt]; }
-            else bq0[ks][nt] = bq2[ks][nt];
+#pragma unroll
+            for (int i = 0; i < BD; ++i) bq[i][ks][nt] = bq[i + 1][ks][nt];
           }
           if (KDIP_A_PREFETCH) {
 #pragma unroll
