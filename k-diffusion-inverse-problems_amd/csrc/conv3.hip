@@ -53,8 +53,14 @@ constexpr int C3_LDS_TOTAL = C3_LDS + 64 + 512;           // + dummy staging slo
 #define C3_BLOCKS_PER_CU 2
 #endif
 constexpr int C3_TABPIX = 336, C3_TABSLOTS = 2 * C3_TABPIX;
-constexpr int c3_max_cin(int tf) { return tf == 1 ? 2 * C3_TABSLOTS : (tf == 2 ? C3_TABSLOTS : (1 << 20)); }
+// TF 2 keeps one float4 (a, b, k0, k1) per channel and uses 320 pixels per buffer, so that a 32-channel chunk never straddles the
+// two buffers; within a chunk channel 8g + e sits in slot 4e + g: the four lane groups g = tid & 3 that read coefficient e of their
+// channel together hit four consecutive pads (80 bytes apart = banks 0-3, 20-23, 40-43, 60-63: conflict-free; the channel-major
+// order put groups 0 / 2 and 1 / 3 on the same banks -- 39 % of the LDS cycles of the TF 2 launches were conflict cycles)
+constexpr int C3_TABPIX2 = 320;
+constexpr int c3_max_cin(int tf) { return tf == 1 ? 2 * C3_TABSLOTS : (tf == 2 ? 2 * C3_TABPIX2 : (1 << 20)); }
 __device__ __forceinline__ int c3_tab_off(int slot) { return (slot / C3_TABPIX) * C3_ABUF + (slot % C3_TABPIX) * C3_PIXB + 64; }
+__device__ __forceinline__ int c3_tab_off2(int slot) { return (slot / C3_TABPIX2) * C3_ABUF + (slot % C3_TABPIX2) * C3_PIXB + 64; }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
       for (int j = tid; j < p.Cin / 2; j += 256) *(float4*)(smem + c3_tab_off(j)) = src[j];
     } else if (TF == 2) {
       const float4* src = (const float4*)(p.tf_coef + (long)im * p.Cin * 4);
-      for (int j = tid; j < p.Cin; j += 256) *(float4*)(smem + c3_tab_off(j)) = src[j];
+      for (int j = tid; j < p.Cin; j += 256) *(float4*)(smem + c3_tab_off2((j & ~31) + (j & 7) * 4 + ((j >> 3) & 3))) = src[j];
     }
     tab_img = im;
   };
@@ -226,14 +232,13 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
       }
       o = pack16<bf16_t>(f);
     } else if (TF == 2) {
-      const int slot = c * 32 + (tid & 3) * 8;                              // 8 consecutive slots: (a, b, k0, k1) per channel
-      const unsigned char* tab = smem + c3_tab_off(slot);
+      const unsigned char* tab = smem + c3_tab_off2(c * 32 + (tid & 3));     // channel 8 (tid & 3) + e of the chunk: slot 4e + (tid & 3)
       float fd[8], fx[8];
       unpack16<bf16_t>(o, fd);
       unpack16<bf16_t>(o2, fx);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {          // the staged tensor already holds dz = dy * silu'(z) (written by the producing epilogue)
-        const float4 k = *(const float4*)(tab + e * C3_PIXB);
+        const float4 k = *(const float4*)(tab + e * 4 * C3_PIXB);
         fd[e] = k.x * fd[e] - (k.z + k.w * fx[e]);
       }
       o = pack16<bf16_t>(fd);
