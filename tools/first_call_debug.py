@@ -4,10 +4,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import smooth_image, synthetic_recon_mse
 import kdip_amd.unet as ku, kdip_amd.measurements as km, kdip_amd.condition as kc
-from oracle import unet as ounet
 sigma_v = float(sys.argv[1]) if len(sys.argv) > 1 else 1.5
-ocfg = ounet.UNetConfig(**ounet.IMAGENET)
-sd = ounet.init_state_dict(ocfg, seed=0)
+sd = ku.synthetic_state_dict(seed=0, **ku.IMAGENET_CONFIG)
 opkw = dict(in_shape=(1, 3, 256, 256), kernel_size=61, intensity=0.5, sigma_s=0.05)
 x0 = smooth_image(2, 256, 1)
 x = x0 + sigma_v * torch.randn(2, 3, 256, 256, generator=torch.Generator().manual_seed(11))
