@@ -49,6 +49,12 @@ constexpr int C3_LDS_TOTAL = C3_LDS + 64 + 512;           // + dummy staging slo
 #ifndef C3_KLOOP_PRIO
 #define C3_KLOOP_PRIO 2        // wave priority inside the K loop (epilogue / tile bookkeeping run at 0): the two blocks of a CU share each
 #endif                         // SIMD's VALU issue port, and an older block's epilogue VALU stream otherwise starves the younger block's MFMAs
+#ifndef C3_NT_STORE
+#define C3_NT_STORE 0          // non-temporal epilogue stores: measured 41.1 -> 43.4 ms per step (the 16-byte pieces of a line no longer merge in L2)
+#endif
+#ifndef C3_NT_AUX
+#define C3_NT_AUX 0            // non-temporal loads of the epilogue's residual / GroupNorm-input rows: measured 41.1 -> 42.1 ms per step
+#endif
 #ifndef C3_BLOCKS_PER_CU
 #define C3_BLOCKS_PER_CU 2
 #endif
@@ -129,6 +135,14 @@ __device__ __forceinline__ f32x16 mfma_bf16(const uint4& a, const uint4& b, cons
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+__device__ __forceinline__ void c3_store(void* p, uint4 o) {
+  if (C3_NT_STORE) { u32x4 v = {o.x, o.y, o.z, o.w}; __builtin_nontemporal_store(v, (u32x4*)p); }
+  else *(uint4*)p = o;
+}
+__device__ __forceinline__ uint4 c3_aux_load(const void* p) {
+  if (C3_NT_AUX) { u32x4 v = __builtin_nontemporal_load((const u32x4*)p); return make_uint4(v[0], v[1], v[2], v[3]); }
+  return *(const uint4*)p;
+}
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
@@ -544,7 +558,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-          for (int k = 0; k < 2; ++k) aux[mt][nt][k] = *(const uint4*)(r + (nt * 32 + 16 * k) * 2);
+          for (int k = 0; k < 2; ++k) aux[mt][nt][k] = c3_aux_load(r + (nt * 32 + 16 * k) * 2);
       }
     } else if (STM == 2) {
       // GroupNorm-input rows in the STORE layout; they are consumed in the second sweep below, so their latency hides under
@@ -556,7 +570,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-          for (int k = 0; k < 2; ++k) aux[mt][nt][k] = *(const uint4*)(xb + mt * rsx + lane_x + (nt * 32 + 16 * k) * 2);
+          for (int k = 0; k < 2; ++k) aux[mt][nt][k] = c3_aux_load(xb + mt * rsx + lane_x + (nt * 32 + 16 * k) * 2);
     }
     float ss[16];                                           // [0..7]: sum 1 per channel quad, [8..15]: sum 2
 #pragma unroll
@@ -599,7 +613,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
           }
           const uint4 o = make_uint4(w0x, w0y, w1x, w1y);
           if (STM == 2) wst[STM == 2 ? mt : 0][nt][k] = o;        // turned into dz and stored by sweep 2
-          else *(uint4*)(yb + mt * rsy + coff + lane_y) = o;
+          else c3_store(yb + mt * rsy + coff + lane_y, o);
     };
     // Order of the 16 (pixel row, channel vector) items.  Row-major is what the memory system wants (above); without a residual
     // it costs 11 - 20 spilled registers in this region and measures 3 - 5 % slower, so those variants keep vector-major order.
@@ -680,7 +694,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
           for (int k = 0; k < 2; ++k)
-            *(uint4*)(yb + mt * rsy + (unsigned)((nt * 32 + 16 * k) * 2) + lane_y) = wst[STM == 2 ? mt : 0][nt][k];
+            c3_store(yb + mt * rsy + (unsigned)((nt * 32 + 16 * k) * 2) + lane_y, wst[STM == 2 ? mt : 0][nt][k]);
     }
     if (first) C3_STAMP(5);
     if (STM) {

@@ -351,6 +351,19 @@ int gn_bwd_stats(hipStream_t st, DType dt, const void* x, long ldx, const void* 
   return KDIP_OK;
 }
 
+#ifndef KDIP_GN_NT
+#define KDIP_GN_NT 2             // gn_bwd_apply: non-temporal loads of dy / addends + store of dx (1), and of x (2): 3.87 -> 4.2-4.3 TB/s in the network; 0: plain
+#endif
+typedef __attribute__((ext_vector_type(4))) unsigned gn_u32x4;
+__device__ __forceinline__ uint4 gn_ld(const void* p) {
+  if (KDIP_GN_NT) { gn_u32x4 v = __builtin_nontemporal_load((const gn_u32x4*)p); return make_uint4(v[0], v[1], v[2], v[3]); }
+  return *(const uint4*)p;
+}
+__device__ __forceinline__ void gn_st(void* p, uint4 o) {
+  if (KDIP_GN_NT) { gn_u32x4 v = {o.x, o.y, o.z, o.w}; __builtin_nontemporal_store(v, (gn_u32x4*)p); }
+  else *(uint4*)p = o;
+}
+
 template <typename T>
 __global__ void gn_bwd_apply_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy, long lddy,
                                     const float* __restrict__ coef, const float* __restrict__ mr,
@@ -385,11 +398,11 @@ __global__ void gn_bwd_apply_kernel(const T* __restrict__ x, long ldx, const T* 
   T* ob = dx + ((long)b * HW) * lddx + (long)vi * EPV;
   for (long p = p0 + pl; p < p1; p += lanes) {
     float fx[EPV], fd[EPV], fa[EPV], fa2[EPV], out[EPV];
-    unpack16<T>(*(const uint4*)(xb + p * ldx), fx);
+    unpack16<T>(KDIP_GN_NT >= 2 ? gn_ld(xb + p * ldx) : *(const uint4*)(xb + p * ldx), fx);
     const long pd = half_lgW >= 0 ? (((p >> half_lgW) >> 1) << (half_lgW - 1)) + ((p & ((1L << half_lgW) - 1)) >> 1) : p;
-    unpack16<T>(*(const uint4*)(db + pd * lddy), fd);
-    if (ab) unpack16<T>(*(const uint4*)(ab + pd * lda), fa);
-    if (ab2) unpack16<T>(*(const uint4*)(ab2 + p * lda2), fa2);
+    unpack16<T>(gn_ld(db + pd * lddy), fd);
+    if (ab) unpack16<T>(gn_ld(ab + pd * lda), fa);
+    if (ab2) unpack16<T>(gn_ld(ab2 + p * lda2), fa2);
 #pragma unroll
     for (int e = 0; e < EPV; ++e) {
       float z = ca[e] * fx[e] + cb[e];
@@ -399,7 +412,7 @@ __global__ void gn_bwd_apply_kernel(const T* __restrict__ x, long ldx, const T* 
       if (ab2) r += fa2[e];
       out[e] = r;
     }
-    *(uint4*)(ob + p * lddx) = pack16<T>(out);
+    gn_st(ob + p * lddx, pack16<T>(out));
   }
 }
 

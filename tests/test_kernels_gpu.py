@@ -150,9 +150,11 @@ def test_unet_tiny_golden(gold, dtype, tol):
     assert rel_err(cov.cpu(), cov_ref) < tol
     vj = m.vjp(torch.from_numpy(g["cot"]).cuda())
     assert rel_err(vj.cpu(), torch.from_numpy(g["vjp"])) < tol
-    # the stash survives: a second VJP gives the same answer (up to fp64-atomic summation order)
+    # the stash survives: a second VJP gives the same answer up to the summation order of the fp64 / fp32 atomics (GroupNorm
+    # backward sums, split-K): f32 mode 1e-5; in bf16 mode a last-bit difference in a coefficient can flip a bf16 rounding of an
+    # activation gradient (one ulp = 2^-8 relative), seen in about one run out of six as 4e-3 of the largest element
     vj2 = m.vjp(torch.from_numpy(g["cot"]).cuda())
-    assert rel_err(vj2, vj) < 1e-5
+    assert rel_err(vj2, vj) < (1e-5 if dtype == "f32" else 2e-2)
 
 
 def test_unet_missing_weight_fails_loudly():
