@@ -71,16 +71,36 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   float m_run = -INFINITY, l_run = 0.f;
+  // software pipeline over key tiles: the K fragments of tile i+1 are requested right after the score MFMAs of tile i have
+  // consumed the current ones, the V^T fragments of tile i at its top -- both round trips hide under the softmax arithmetic
+  uint4 kf[4][2];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    kf[s][0] = *(const uint4*)(kb + (long)n * p.ld + 16 * s);
+    kf[s][1] = *(const uint4*)(kb + (long)(32 + n) * p.ld + 16 * s);
+  }
   for (int k0 = 0; k0 < p.T; k0 += 64) {
+    uint4 vf[4][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      vf[ks][0] = *(const uint4*)(vtb + (long)n * p.T + k0 + 16 * ks);
+      vf[ks][1] = *(const uint4*)(vtb + (long)(32 + n) * p.T + k0 + 16 * ks);
+    }
     f32x16 s0, s1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const uint4 ka = *(const uint4*)(kb + (long)(k0 + n) * p.ld + 16 * s);
-      const uint4 kc = *(const uint4*)(kb + (long)(k0 + 32 + n) * p.ld + 16 * s);
-      s0 = mma(ka, qf[s], s0);
-      s1 = mma(kc, qf[s], s1);
+      s0 = mma(kf[s][0], qf[s], s0);
+      s1 = mma(kf[s][1], qf[s], s1);
+    }
+    {
+      const int kn = k0 + 64 < p.T ? k0 + 64 : k0;          // (last tile: a redundant reload keeps the loop branch-free)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        kf[s][0] = *(const uint4*)(kb + (long)(kn + n) * p.ld + 16 * s);
+        kf[s][1] = *(const uint4*)(kb + (long)(kn + 32 + n) * p.ld + 16 * s);
+      }
     }
     float mx = s0[0];
 #pragma unroll
@@ -100,10 +120,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const uint4 pf = rows_to_b(ks < 2 ? s0 : s1, ks & 1);          // keys k0 + 16 ks + 8h .. + 7 of this lane's query
-      const uint4 va = *(const uint4*)(vtb + (long)n * p.T + k0 + 16 * ks);
-      const uint4 vc = *(const uint4*)(vtb + (long)(32 + n) * p.T + k0 + 16 * ks);
-      o0 = mma(va, pf, o0);
-      o1 = mma(vc, pf, o1);
+      o0 = mma(vf[ks][0], pf, o0);
+      o1 = mma(vf[ks][1], pf, o1);
     }
   }
   const float l_tot = l_run + other_half(l_run);
@@ -156,26 +174,42 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBP p) {
   f32x16 g0, g1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { g0[r] = 0.f; g1[r] = 0.f; }
+  uint4 ka[4], va[4];                                   // K / V fragments of the current key tile, requested one tile ahead
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    ka[s] = *(const uint4*)(kb + (long)n * p.ld + 16 * s);
+    va[s] = *(const uint4*)(vb + (long)n * p.ld + 16 * s);
+  }
   for (int k0 = 0; k0 < p.T; k0 += 32) {
+    uint4 ta[2], tc[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      ta[ks] = *(const uint4*)(ktb + (long)n * p.T + k0 + 16 * ks);
+      tc[ks] = *(const uint4*)(ktb + (long)(32 + n) * p.T + k0 + 16 * ks);
+    }
     f32x16 st, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const uint4 ka = *(const uint4*)(kb + (long)(k0 + n) * p.ld + 16 * s);
-      const uint4 va = *(const uint4*)(vb + (long)(k0 + n) * p.ld + 16 * s);
-      st = mma(ka, qf[s], st);
-      dp = mma(va, dof[s], dp);
+      st = mma(ka[s], qf[s], st);
+      dp = mma(va[s], dof[s], dp);
+    }
+    {
+      const int kn = k0 + 32 < p.T ? k0 + 32 : k0;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        ka[s] = *(const uint4*)(kb + (long)(kn + n) * p.ld + 16 * s);
+        va[s] = *(const uint4*)(vb + (long)(kn + n) * p.ld + 16 * s);
+      }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[r] = ex2(st[r] * p.c - Lq) * (dp[r] - Dq);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const uint4 dsf = rows_to_b(st, ks);
-      const uint4 ta = *(const uint4*)(ktb + (long)n * p.T + k0 + 16 * ks);
-      const uint4 tc = *(const uint4*)(ktb + (long)(32 + n) * p.T + k0 + 16 * ks);
-      g0 = mma(ta, dsf, g0);
-      g1 = mma(tc, dsf, g1);
+      g0 = mma(ta[ks], dsf, g0);
+      g1 = mma(tc[ks], dsf, g1);
     }
   }
 #pragma unroll
@@ -208,23 +242,47 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBP p) {
   f32x16 k0a, k1a, v0a, v1a;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { k0a[r] = 0.f; k1a[r] = 0.f; v0a[r] = 0.f; v1a[r] = 0.f; }
+  uint4 qa[4], da[4];                                   // Q / dO fragments of the current query tile, requested one tile ahead
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    qa[s] = *(const uint4*)(base + (long)n * p.ld + 16 * s);
+    da[s] = *(const uint4*)(dob + (long)n * p.lddo + 16 * s);
+  }
   for (int q0 = 0; q0 < p.T; q0 += 32) {
+    uint4 dta[2], dtc[2], qta[2], qtc[2];
+    float4 Lr[4], Dr[4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      dta[ks] = *(const uint4*)(dtb + (long)n * p.T + q0 + 16 * ks);
+      dtc[ks] = *(const uint4*)(dtb + (long)(32 + n) * p.T + q0 + 16 * ks);
+      qta[ks] = *(const uint4*)(qtb + (long)n * p.T + q0 + 16 * ks);
+      qtc[ks] = *(const uint4*)(qtb + (long)(32 + n) * p.T + q0 + 16 * ks);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {          // rows (queries) q0 + 8g + 4h + j of this lane
+      Lr[g] = *(const float4*)(p.lse + hrow + q0 + 8 * g + 4 * h);
+      Dr[g] = *(const float4*)(p.D + hrow + q0 + 8 * g + 4 * h);
+    }
     f32x16 st, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const uint4 qa = *(const uint4*)(base + (long)(q0 + n) * p.ld + 16 * s);
-      const uint4 da = *(const uint4*)(dob + (long)(q0 + n) * p.lddo + 16 * s);
-      st = mma(qa, kf[s], st);
-      dp = mma(da, vf[s], dp);
+      st = mma(qa[s], kf[s], st);
+      dp = mma(da[s], vf[s], dp);
+    }
+    {
+      const int qn = q0 + 32 < p.T ? q0 + 32 : q0;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        qa[s] = *(const uint4*)(base + (long)(qn + n) * p.ld + 16 * s);
+        da[s] = *(const uint4*)(dob + (long)(qn + n) * p.lddo + 16 * s);
+      }
     }
     f32x16 ds;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {          // rows (queries) q0 + 8g + 4h + j of this lane
-      const float4 Lr = *(const float4*)(p.lse + hrow + q0 + 8 * g + 4 * h);
-      const float4 Dr = *(const float4*)(p.D + hrow + q0 + 8 * g + 4 * h);
-      const float lr[4] = {Lr.x, Lr.y, Lr.z, Lr.w}, dr[4] = {Dr.x, Dr.y, Dr.z, Dr.w};
+    for (int g = 0; g < 4; ++g) {
+      const float lr[4] = {Lr[g].x, Lr[g].y, Lr[g].z, Lr[g].w}, dr[4] = {Dr[g].x, Dr[g].y, Dr[g].z, Dr[g].w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float pr = ex2(st[4 * g + j] * p.c - lr[j]);
@@ -235,12 +293,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBP p) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const uint4 pB = rows_to_b(st, ks), dB = rows_to_b(ds, ks);
-      const uint4 da = *(const uint4*)(dtb + (long)n * p.T + q0 + 16 * ks);
-      const uint4 dc = *(const uint4*)(dtb + (long)(32 + n) * p.T + q0 + 16 * ks);
-      const uint4 qa = *(const uint4*)(qtb + (long)n * p.T + q0 + 16 * ks);
-      const uint4 qc = *(const uint4*)(qtb + (long)(32 + n) * p.T + q0 + 16 * ks);
-      v0a = mma(da, pB, v0a); v1a = mma(dc, pB, v1a);
-      k0a = mma(qa, dB, k0a); k1a = mma(qc, dB, k1a);
+      v0a = mma(dta[ks], pB, v0a); v1a = mma(dtc[ks], pB, v1a);
+      k0a = mma(qta[ks], dB, k0a); k1a = mma(qtc[ks], dB, k1a);
     }
   }
 #pragma unroll
