@@ -85,6 +85,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef C3_ABL_NOLDSR
 #define C3_ABL_NOLDSR 0
 #endif
+#ifndef C3_ABL_EPI_NOSILU
+#define C3_ABL_EPI_NOSILU 0    // backward-statistics epilogue without the silu' transcendentals (timing ablation)
+#endif
 #ifndef C3_ABL_NOTF
 #define C3_ABL_NOTF 0
 #endif
@@ -666,7 +669,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
               const float4 kk = ka[e >> 1];
               const float a = (e & 1) ? kk.z : kk.x, b = (e & 1) ? kk.w : kk.y;
               const float z = a * xg[e] + b;
-              dzv[e] = dy[e] * silu_grad_fast(z);
+              dzv[e] = dy[e] * (C3_ABL_EPI_NOSILU ? z : silu_grad_fast(z));
               const float adz = a * dzv[e];
               t1[e >> 2] += adz;
               t2[e >> 2] += adz * xg[e];
