@@ -55,6 +55,9 @@ constexpr int C3_LDS_TOTAL = C3_LDS + 64 + 512;           // + dummy staging slo
 #ifndef C3_NT_AUX
 #define C3_NT_AUX 0            // non-temporal loads of the epilogue's residual / GroupNorm-input rows: measured 41.1 -> 42.1 ms per step
 #endif
+#ifndef C3_STAGGER
+#define C3_STAGGER 0            // experiment: start delay of block j = (j / 8 % 16) * C3_STAGGER * 64 cycles (de-synchronises the chip-wide epilogue bursts)
+#endif
 #ifndef C3_BLOCKS_PER_CU
 #define C3_BLOCKS_PER_CU 2
 #endif
@@ -167,6 +170,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
   const int nper = gridDim.x >> 3;                       // blocks per XCD share
   int cur = xstart + (blockIdx.x >> 3);
   if (cur >= xend) return;
+  if (C3_STAGGER) { for (int i = (int)((blockIdx.x >> 3) & 15); i > 0; --i) __builtin_amdgcn_s_sleep(C3_STAGGER); }
   C3_STAMP(0);
 #if C3_TIMING
   if (p.dbg && threadIdx.x == 0 && STM == 0)              // slot 7 (unused without statistics): shader-clock counter at block start
