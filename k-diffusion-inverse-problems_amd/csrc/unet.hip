@@ -35,7 +35,7 @@ static inline int pad32(int c) { return (c + 31) / 32 * 32; }
 // guided_diffusion/unet.py:199-205,472-477: M = batch, latency-bound).
 __global__ void linear_f32_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                   const float* __restrict__ bias, int B, int in, int out, int silu_in,
-                                  float* __restrict__ y) {
+                                  float* __restrict__ y, int silu_out) {
   // one wave per 4 output features, 8 batch rows at a time: each weight row is streamed once and every (L2-resident)
   // input row is re-read by out/4 waves instead of out
   constexpr int OC = 4, BT = 8;
@@ -66,13 +66,16 @@ __global__ void linear_f32_kernel(const float* __restrict__ x, const float* __re
 #pragma unroll
       for (int j = 0; j < BT; ++j) {
         const float t = wave_sum(s[o][j]);
-        if (lane == 0 && oc0 + o < out && b0 + j < B) y[(long)(b0 + j) * out + oc0 + o] = t + bias[oc0 + o];
+        if (lane == 0 && oc0 + o < out && b0 + j < B) {
+          const float v = t + bias[oc0 + o];
+          y[(long)(b0 + j) * out + oc0 + o] = silu_out ? v / (1.f + expf(-v)) : v;      // (silu_out: the consumer applies SiLU to every
+        }                                                                                //  element once per OUTPUT block otherwise)
       }
   }
 }
-static int linear_f32(hipStream_t st, const float* x, const LinW& L, int B, int silu_in, float* y) {
+static int linear_f32(hipStream_t st, const float* x, const LinW& L, int B, int silu_in, float* y, int silu_out = 0) {
   hipLaunchKernelGGL(linear_f32_kernel, dim3(cdiv((long)L.out, 16)), dim3(256), 0, st, x, L.w, L.b, B, L.in, L.out,
-                     silu_in, y);
+                     silu_in, y, silu_out);
   KDIP_LAUNCH_CHECK();
   return KDIP_OK;
 }
@@ -585,10 +588,10 @@ int UNet::forward_impl(hipStream_t st, const float* x_nchw, const float* t, int 
   float* e1 = (float*)persist.alloc(sizeof(float) * B * ted);
   float* emb = (float*)persist.alloc(sizeof(float) * B * ted);
   RUN(timestep_embedding(st, t, B, mc, temb));
-  RUN(linear_f32(st, temb, te0, B, 0, e1));
-  RUN(linear_f32(st, e1, te2, B, 1, emb));
+  RUN(linear_f32(st, temb, te0, B, 0, e1, 1));               // e1 = SiLU(te0(temb)): the activation is applied once, by the producer
+  RUN(linear_f32(st, e1, te2, B, 0, emb, 1));                // emb is only ever consumed through SiLU (every ResBlock's emb_layers)
   float* film_all = (float*)persist.alloc(sizeof(float) * (size_t)B * emb_total);
-  RUN(linear_f32(st, emb, emb_all, B, 1, film_all));       // every ResBlock's Linear(SiLU(emb)) in one launch
+  RUN(linear_f32(st, emb, emb_all, B, 0, film_all));       // every ResBlock's Linear(SiLU(emb)) in one launch
   // input: NCHW fp32 * c_in -> NHWC T, channels padded to 32
   void* xin = persist.alloc(es * (size_t)B * H * W * 32);
   RUN(nchw_to_nhwc(st, dt, x_nchw, B, cfg.in_channels, H, W, in_scale, xin, 32, 32));
