@@ -15,8 +15,9 @@
 // contiguous per lane, i.e. V^T, K^T, Q^T, dO^T: small per-head transposes ([64][T] per (image, head)) written by
 // head_transpose_kernel just before (B*T*C elements each; the score matrices they replace are T/64 times larger).
 //
-// One wave owns 32 tokens (queries, or keys in the dK/dV kernel) and streams the other side in tiles straight from global
-// memory (L2-resident: K/V of one (image, head) are 2 x T x 128 bytes); waves do not communicate, so there are no barriers.
+// One wave owns 32 tokens (queries, or keys in the dK/dV kernel).  Two families of kernels: the direct ones stream the other side
+// in tiles straight from global memory, wave by wave, no barriers (kept as the KDIP_ATTN_LDS=0 reference); the shipped ones stage
+// the tiles through LDS for the 4 waves of a block (further down: 2 x faster at T = 1024).
 #include "kernels.h"
 
 namespace kdip {
@@ -309,6 +310,292 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS-staged variants (KDIP_ATTN_LDS, default): the tiles of the streamed side are copied global -> LDS by the whole block with
+// row-contiguous 16-byte loads (8 lanes per 128-byte row; the direct variants above fetch every fragment with one row per lane
+// pair, 32 segments per wave instruction, and every one of the 4 waves fetches the same data) and all 4 waves read their MFMA
+// fragments from there.  Rows are padded by 16 bytes (144- / 80-byte pitch: 16 consecutive rows fall on 16 distinct 4-bank
+// groups, conflict-free ds_read_b128).  Double-buffered: tile i+1 is in flight in registers while tile i is consumed, one
+// barrier per tile.  Waves whose 32 tokens lie beyond T (T = 64: two of four) only help with the copies.
+#ifndef KDIP_ATTN_LDS
+#define KDIP_ATTN_LDS 1
+#endif
+constexpr int AT_P64 = 144, AT_P32 = 80;              // LDS row pitch (bytes) of 64- / 32-element bf16 rows
+
+// [64][64] / [32][64] bf16 tile, global row stride ld (elements): registers <- global, LDS <- registers (plain structs, not
+// arrays: hipcc otherwise "promotes" the staging arrays of the three-tile kernel to 24 KB of LDS)
+struct Stage2 { uint4 a, b; };
+__device__ __forceinline__ Stage2 tile64_load(const bf16_t* src, long ld, int tid) {
+  Stage2 r;
+  r.a = *(const uint4*)(src + (long)(tid >> 3) * ld + (tid & 7) * 8);
+  r.b = *(const uint4*)(src + (long)(32 + (tid >> 3)) * ld + (tid & 7) * 8);
+  return r;
+}
+__device__ __forceinline__ void tile64_store(unsigned char* lds, const Stage2& r, int tid) {
+  *(uint4*)(lds + (tid >> 3) * AT_P64 + (tid & 7) * 16) = r.a;
+  *(uint4*)(lds + (32 + (tid >> 3)) * AT_P64 + (tid & 7) * 16) = r.b;
+}
+__device__ __forceinline__ uint4 tile32x64_load(const bf16_t* src, long ld, int tid) { return *(const uint4*)(src + (long)(tid >> 3) * ld + (tid & 7) * 8); }
+__device__ __forceinline__ void tile32x64_store(unsigned char* lds, uint4 r, int tid) { *(uint4*)(lds + (tid >> 3) * AT_P64 + (tid & 7) * 16) = r; }
+// [64][32] bf16 tile (64 rows of 64 bytes): one 16-byte vector per thread
+__device__ __forceinline__ uint4 tile32_load(const bf16_t* src, long ld, int tid) { return *(const uint4*)(src + (long)(tid >> 2) * ld + (tid & 3) * 8); }
+__device__ __forceinline__ void tile32_store(unsigned char* lds, uint4 r, int tid) { *(uint4*)(lds + (tid >> 2) * AT_P32 + (tid & 3) * 16) = r; }
+// MFMA operand fragment of lane (n, h): row n of a 32-row block, elements 16 s + 8 h .. + 7
+__device__ __forceinline__ uint4 frag64(const unsigned char* lds, int row, int s, int h) { return *(const uint4*)(lds + row * AT_P64 + (16 * s + 8 * h) * 2); }
+__device__ __forceinline__ uint4 frag32(const unsigned char* lds, int row, int s, int h) { return *(const uint4*)(lds + row * AT_P32 + (16 * s + 8 * h) * 2); }
+
+__global__ __launch_bounds__(256) void attn_fwd_lds_kernel(AttnP p) {
+  __shared__ __attribute__((aligned(16))) unsigned char sm[2][2][64 * AT_P64];          // [buffer][K | V^T][rows]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5;
+  const int q0 = (blockIdx.x * 4 + wave) * 32;
+  const bool active = q0 < p.T;
+  const int qrow = active ? q0 + n : n;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const bf16_t* base = p.qkv + (long)b * p.T * p.ld + head * 192;
+  uint4 qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) qf[s] = *(const uint4*)(base + (long)qrow * p.ld + 8 * h + 16 * s);
+  const bf16_t* kb = base + 64;
+  const bf16_t* vtb = p.vt + ((long)(b * p.heads + head) * 64) * p.T;
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  float m_run = -INFINITY, l_run = 0.f;
+  Stage2 kr = tile64_load(kb, p.ld, tid), vr = tile64_load(vtb, p.T, tid);
+  tile64_store(sm[0][0], kr, tid);
+  tile64_store(sm[0][1], vr, tid);
+  __syncthreads();
+  const int ntile = p.T >> 6;
+  for (int it = 0; it < ntile; ++it) {
+    const unsigned char* kl = sm[it & 1][0];
+    const unsigned char* vl = sm[it & 1][1];
+    const bool more = it + 1 < ntile;
+    if (more) {
+      kr = tile64_load(kb + (long)(it + 1) * 64 * p.ld, p.ld, tid);
+      vr = tile64_load(vtb + (it + 1) * 64, p.T, tid);
+    }
+    if (active) {
+      f32x16 s0, s1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        s0 = mma(frag64(kl, n, s, h), qf[s], s0);
+        s1 = mma(frag64(kl, 32 + n, s, h), qf[s], s1);
+      }
+      float mx = s0[0];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { mx = fmaxf(mx, s0[r]); mx = fmaxf(mx, s1[r]); }
+      mx = fmaxf(mx, other_half(mx));
+      const float m_new = fmaxf(m_run, mx * p.c);
+      const float corr = ex2(m_run - m_new);
+      m_run = m_new;
+      float ls = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s0[r] = ex2(s0[r] * p.c - m_new); s1[r] = ex2(s1[r] * p.c - m_new);
+        ls += s0[r] + s1[r];
+        o0[r] *= corr; o1[r] *= corr;
+      }
+      l_run = l_run * corr + ls;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const uint4 pf = rows_to_b(ks < 2 ? s0 : s1, ks & 1);
+        o0 = mma(frag64(vl, n, ks, h), pf, o0);
+        o1 = mma(frag64(vl, 32 + n, ks, h), pf, o1);
+      }
+    }
+    if (more) {
+      tile64_store(sm[(it + 1) & 1][0], kr, tid);
+      tile64_store(sm[(it + 1) & 1][1], vr, tid);
+    }
+    __syncthreads();
+  }
+  if (!active) return;
+  const float l_tot = l_run + other_half(l_run);
+  const float inv = 1.f / l_tot;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] *= inv; o1[r] *= inv; }
+  bf16_t* orow = p.o + ((long)b * p.T + q0 + n) * p.ldo + head * 64 + 8 * h;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    *(uint4*)(orow + 16 * s) = rows_to_b(o0, s);
+    *(uint4*)(orow + 32 + 16 * s) = rows_to_b(o1, s);
+  }
+  if (h == 0) p.lse[((long)b * p.heads + head) * p.T + q0 + n] = m_run + __log2f(l_tot);
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dq_lds_kernel(AttnBP p) {
+  __shared__ __attribute__((aligned(16))) unsigned char sm[2][3][64 * AT_P64];          // [buffer][K | V | K^T][rows]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5;
+  const int q0 = (blockIdx.x * 4 + wave) * 32;
+  const bool active = q0 < p.T;
+  const int qrow = active ? q0 + n : n;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const bf16_t* base = p.qkv + (long)b * p.T * p.ld + head * 192;
+  const bf16_t* dorow = p.dO + ((long)b * p.T + qrow) * p.lddo + head * 64 + 8 * h;
+  const bf16_t* orow = p.o + ((long)b * p.T + qrow) * p.ldo + head * 64 + 8 * h;
+  uint4 qf[4], dof[4];
+  float dpart = 0.f;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    qf[s] = *(const uint4*)(base + (long)qrow * p.ld + 8 * h + 16 * s);
+    dof[s] = *(const uint4*)(dorow + 16 * s);
+    dpart += dot8(dof[s], *(const uint4*)(orow + 16 * s));
+  }
+  const float Dq = dpart + other_half(dpart);
+  const long row = ((long)b * p.heads + head) * p.T + qrow;
+  if (active && h == 0) p.D[row] = Dq;
+  const float Lq = p.lse[row];
+  const bf16_t* kb = base + 64;
+  const bf16_t* vb = base + 128;
+  const bf16_t* ktb = p.kt + ((long)(b * p.heads + head) * 64) * p.T;
+  f32x16 g0, g1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { g0[r] = 0.f; g1[r] = 0.f; }
+  Stage2 kr = tile64_load(kb, p.ld, tid), vr = tile64_load(vb, p.ld, tid), tr = tile64_load(ktb, p.T, tid);
+  tile64_store(sm[0][0], kr, tid); tile64_store(sm[0][1], vr, tid); tile64_store(sm[0][2], tr, tid);
+  __syncthreads();
+  const int ntile = p.T >> 6;
+  for (int it = 0; it < ntile; ++it) {
+    const unsigned char* kl = sm[it & 1][0];
+    const unsigned char* vl = sm[it & 1][1];
+    const unsigned char* tl = sm[it & 1][2];
+    const bool more = it + 1 < ntile;
+    if (more) {
+      kr = tile64_load(kb + (long)(it + 1) * 64 * p.ld, p.ld, tid);
+      vr = tile64_load(vb + (long)(it + 1) * 64 * p.ld, p.ld, tid);
+      tr = tile64_load(ktb + (it + 1) * 64, p.T, tid);
+    }
+    if (active) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {                 // two 32-key halves of the staged tile
+        f32x16 st, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          st = mma(frag64(kl, 32 * sub + n, s, h), qf[s], st);
+          dp = mma(frag64(vl, 32 * sub + n, s, h), dof[s], dp);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = ex2(st[r] * p.c - Lq) * (dp[r] - Dq);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const uint4 dsf = rows_to_b(st, ks);
+          g0 = mma(frag64(tl, n, 2 * sub + ks, h), dsf, g0);
+          g1 = mma(frag64(tl, 32 + n, 2 * sub + ks, h), dsf, g1);
+        }
+      }
+    }
+    if (more) {
+      tile64_store(sm[(it + 1) & 1][0], kr, tid); tile64_store(sm[(it + 1) & 1][1], vr, tid); tile64_store(sm[(it + 1) & 1][2], tr, tid);
+    }
+    __syncthreads();
+  }
+  if (!active) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { g0[r] *= p.alpha; g1[r] *= p.alpha; }
+  bf16_t* grow = p.dqkv + ((long)b * p.T + q0 + n) * p.ldg + head * 192 + 8 * h;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    *(uint4*)(grow + 16 * s) = rows_to_b(g0, s);
+    *(uint4*)(grow + 32 + 16 * s) = rows_to_b(g1, s);
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(AttnBP p) {
+  // per stage (32 queries): Q and dO rows [32][64] (144-byte pitch), Q^T and dO^T [64][32] (80-byte pitch)
+  __shared__ __attribute__((aligned(16))) unsigned char sm[2][2 * 32 * AT_P64 + 2 * 64 * AT_P32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5;
+  const int key0 = (blockIdx.x * 4 + wave) * 32;
+  const bool active = key0 < p.T;
+  const int krow = active ? key0 + n : n;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const bf16_t* base = p.qkv + (long)b * p.T * p.ld + head * 192;
+  uint4 kf[4], vf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    kf[s] = *(const uint4*)(base + 64 + (long)krow * p.ld + 8 * h + 16 * s);
+    vf[s] = *(const uint4*)(base + 128 + (long)krow * p.ld + 8 * h + 16 * s);
+  }
+  const bf16_t* dob = p.dO + (long)b * p.T * p.lddo + head * 64;
+  const long hrow = ((long)b * p.heads + head) * p.T;
+  const bf16_t* qtb = p.qt + hrow * 64;
+  const bf16_t* dtb = p.dot + hrow * 64;
+  constexpr int OQ = 0, OD = 32 * AT_P64, OQT = 2 * 32 * AT_P64, ODT = OQT + 64 * AT_P32;
+  f32x16 k0a, k1a, v0a, v1a;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { k0a[r] = 0.f; k1a[r] = 0.f; v0a[r] = 0.f; v1a[r] = 0.f; }
+  uint4 qr, dr, qtr, dtr;
+  auto load_stage = [&](int q0) {
+    qr = tile32x64_load(base + (long)q0 * p.ld, p.ld, tid);
+    dr = tile32x64_load(dob + (long)q0 * p.lddo, p.lddo, tid);
+    qtr = tile32_load(qtb + q0, p.T, tid);
+    dtr = tile32_load(dtb + q0, p.T, tid);
+  };
+  auto store_stage = [&](unsigned char* s_) {
+    tile32x64_store(s_ + OQ, qr, tid); tile32x64_store(s_ + OD, dr, tid);
+    tile32_store(s_ + OQT, qtr, tid); tile32_store(s_ + ODT, dtr, tid);
+  };
+  load_stage(0);
+  store_stage(sm[0]);
+  __syncthreads();
+  const int ntile = p.T >> 5;
+  for (int it = 0; it < ntile; ++it) {
+    const unsigned char* sl = sm[it & 1];
+    const int q0 = it * 32;
+    const bool more = it + 1 < ntile;
+    if (more) load_stage(q0 + 32);
+    if (active) {
+      float4 Lr[4], Dr[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {          // rows (queries) q0 + 8g + 4h + j of this lane
+        Lr[g] = *(const float4*)(p.lse + hrow + q0 + 8 * g + 4 * h);
+        Dr[g] = *(const float4*)(p.D + hrow + q0 + 8 * g + 4 * h);
+      }
+      f32x16 st, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        st = mma(frag64(sl + OQ, n, s, h), kf[s], st);
+        dp = mma(frag64(sl + OD, n, s, h), vf[s], dp);
+      }
+      f32x16 ds;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float lr[4] = {Lr[g].x, Lr[g].y, Lr[g].z, Lr[g].w}, dd[4] = {Dr[g].x, Dr[g].y, Dr[g].z, Dr[g].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float pr = ex2(st[4 * g + j] * p.c - lr[j]);
+          st[4 * g + j] = pr;
+          ds[4 * g + j] = pr * (dp[4 * g + j] - dd[j]);
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const uint4 pB = rows_to_b(st, ks), dB = rows_to_b(ds, ks);
+        v0a = mma(frag32(sl + ODT, n, ks, h), pB, v0a); v1a = mma(frag32(sl + ODT, 32 + n, ks, h), pB, v1a);
+        k0a = mma(frag32(sl + OQT, n, ks, h), dB, k0a); k1a = mma(frag32(sl + OQT, 32 + n, ks, h), dB, k1a);
+      }
+    }
+    if (more) store_stage(sm[(it + 1) & 1]);
+    __syncthreads();
+  }
+  if (!active) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { k0a[r] *= p.alpha; k1a[r] *= p.alpha; }
+  bf16_t* grow = p.dqkv + ((long)b * p.T + key0 + n) * p.ldg + head * 192 + 8 * h;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    *(uint4*)(grow + 64 + 16 * s) = rows_to_b(k0a, s);
+    *(uint4*)(grow + 96 + 16 * s) = rows_to_b(k1a, s);
+    *(uint4*)(grow + 128 + 16 * s) = rows_to_b(v0a, s);
+    *(uint4*)(grow + 160 + 16 * s) = rows_to_b(v1a, s);
+  }
+}
+
 // out[b][head][d][t] = in[b][t][head * hstride + off + d], d < 64; one block = 64 tokens of one (image, head)
 __global__ __launch_bounds__(256) void head_transpose_kernel(const bf16_t* __restrict__ in, long ld, int hstride, int off, int T, int heads,
                                                             bf16_t* __restrict__ out) {
@@ -359,7 +646,8 @@ int attn_fused_forward(hipStream_t st, const void* qkv, long ld, int B, int T, i
   int rc = head_transpose(st, qkv, ld, 192, 128, B, T, heads, vt_ws);
   if (rc) return rc;
   AttnP p{(const bf16_t*)qkv, ld, (const bf16_t*)vt_ws, (bf16_t*)o, ldo, lse, T, heads, 1.4426950408889634f / 8.f};
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((T + 127) / 128, heads, B), dim3(256), 0, st, p);
+  if (KDIP_ATTN_LDS) hipLaunchKernelGGL(attn_fwd_lds_kernel, dim3((T + 127) / 128, heads, B), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(attn_fwd_kernel, dim3((T + 127) / 128, heads, B), dim3(256), 0, st, p);
   KDIP_LAUNCH_CHECK();
   return KDIP_OK;
 }
@@ -377,8 +665,13 @@ int attn_fused_backward(hipStream_t st, const void* qkv, long ld, const void* dO
   AttnBP p{(const bf16_t*)qkv, ld, (const bf16_t*)dO, lddo, (const bf16_t*)o, ldo, lse, D, kt, qt, dot, (bf16_t*)dqkv, ldg, T, heads,
            1.4426950408889634f / 8.f, 0.125f};
   const dim3 grid((T + 127) / 128, heads, B);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, st, p);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, st, p);
+  if (KDIP_ATTN_LDS) {
+    hipLaunchKernelGGL(attn_bwd_dq_lds_kernel, grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL(attn_bwd_dkv_lds_kernel, grid, dim3(256), 0, st, p);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, st, p);
+  }
   KDIP_LAUNCH_CHECK();
   return KDIP_OK;
 }
