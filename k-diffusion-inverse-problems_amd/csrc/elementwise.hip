@@ -162,6 +162,25 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, int B, int C, l
                                     long ld, int Cpad) {
   constexpr int EPV = TypeInfo<T>::EPV;
   long n = (long)B * HW;
+  if (Cpad % EPV == 0 && C <= EPV && (ld * (long)sizeof(T)) % 16 == 0) {
+    // few real channels (the 3-channel image, 6-channel cotangent in bf16): one thread per 16-byte vector of the padded row, so that
+    // consecutive lanes store consecutive 16 bytes (one thread per pixel wrote 4 vectors 64 bytes apart per instruction)
+    const int nv = Cpad / EPV;
+    const long nvec = n * nv;
+    for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < nvec; j += (long)gridDim.x * blockDim.x) {
+      const long i = j / nv; const int v = (int)(j - i * nv);
+      uint4 o = make_uint4(0, 0, 0, 0);
+      if (v == 0) {
+        const long b = i / HW, p = i % HW;
+        float f[EPV];
+#pragma unroll
+        for (int c = 0; c < EPV; ++c) f[c] = c < C ? x[(b * C + c) * HW + p] * scale : 0.f;
+        o = pack16<T>(f);
+      }
+      *(uint4*)(y + i * ld + (long)v * EPV) = o;
+    }
+    return;
+  }
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     long b = i / HW, p = i % HW;
     T* o = y + i * ld;
@@ -195,7 +214,15 @@ __global__ void nhwc_to_nchw_kernel(const T* __restrict__ x, long ld, int B, int
   long n = (long)B * HW;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     long b = i / HW, p = i % HW;
-    for (int c = 0; c < C; ++c) y[(b * C + c) * HW + p] = to_f32(x[i * ld + c]);
+    if (sizeof(T) == 4 && C <= 8 && ld % 4 == 0) {       // fp32 rows padded to 32 channels, 3 / 6 used: two 16-byte loads instead of C scalar ones
+      const float4 lo = *(const float4*)((const float*)x + i * ld);
+      const float4 hi = C > 4 ? *(const float4*)((const float*)x + i * ld + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+      for (int c = 0; c < 8; ++c) if (c < C) y[(b * C + c) * HW + p] = v[c];
+    } else {
+      for (int c = 0; c < C; ++c) y[(b * C + c) * HW + p] = to_f32(x[i * ld + c]);
+    }
   }
 }
 int nhwc_to_nchw_f32(hipStream_t st, const float* x, long ld, int B, int C, int H, int W, float* y) {
