@@ -95,6 +95,12 @@ int conv_debug_timing(void* buf, int H, int cin, int cout, int st_mode) {
 #endif
 
 constexpr int KC = 32;            // input channels per B-pipeline stage (one tap of one 32-channel sub-chunk)
+#ifndef KDIP_CONV1_NT_LOAD
+#define KDIP_CONV1_NT_LOAD 0     // non-temporal input staging loads of the 1x1 convs: big-map class -3 %, small-map classes +2-4 %, step unchanged
+#endif
+#ifndef KDIP_CONV_NT_STORE
+#define KDIP_CONV_NT_STORE 0     // non-temporal output stores of the bf16 epilogue (a wave instruction writes whole 128-byte lines here): measured neutral (40.36 vs 40.47 ms per step)
+#endif
 #ifndef KDIP_B_DEPTH_SMALL
 #define KDIP_B_DEPTH_SMALL 2      // B-fragment stages in flight for the one- / two-MFMA-tile-per-wave configurations (small-map layers);
 #endif                           // 4 and 6 measured the same 19 - 32 us per launch as 2: not bound by the weight stream latency
@@ -229,7 +235,13 @@ __device__ __forceinline__ void epilogue_bf16_fast(const ConvParams& p, f32x16 (
         for (int e = 0; e < 8; ++e) v[e] += rf[e];
       }
       const uint4 o = pack16<bf16_t>(v);
-      *(uint4*)(yout + (long)pix[it] * p.ldy + nl) = o;
+      if (KDIP_CONV_NT_STORE) {
+        typedef __attribute__((ext_vector_type(4))) unsigned cu32x4;
+        cu32x4 ov = {o.x, o.y, o.z, o.w};
+        __builtin_nontemporal_store(ov, (cu32x4*)(yout + (long)pix[it] * p.ldy + nl));
+      } else {
+        *(uint4*)(yout + (long)pix[it] * p.ldy + nl) = o;
+      }
       if (MODE == 1) {
         float vv[8];
         unpack16<bf16_t>(o, vv);                      // statistics of the stored (rounded) values
@@ -464,7 +476,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       areg[i] = make_uint4(0, 0, 0, 0);
-      if (goff[i] >= 0) areg[i] = *(const uint4*)(xin + (long)goff[i] * (16 / (int)sizeof(T)) + (long)c * KCH);
+      if (goff[i] >= 0) {
+        if (KDIP_CONV1_NT_LOAD && NTAPS == 1) {       // 1x1: every input element is read exactly once by this launch
+          typedef __attribute__((ext_vector_type(4))) unsigned cu32x4;
+          const cu32x4 v = __builtin_nontemporal_load((const cu32x4*)(xin + (long)goff[i] * (16 / (int)sizeof(T)) + (long)c * KCH));
+          areg[i] = make_uint4(v[0], v[1], v[2], v[3]);
+        } else {
+          areg[i] = *(const uint4*)(xin + (long)goff[i] * (16 / (int)sizeof(T)) + (long)c * KCH);
+        }
+      }
     }
   };
   auto stage_write = [&](int buf) {
