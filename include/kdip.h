@@ -63,9 +63,12 @@ int kdip_unet_forward(kdip_unet* u, void* stream, const float* x_dev, const floa
  * gx_dev [B,in_ch,S,S] fp32; B must equal the batch of that forward (KDIP_ERR_ARG otherwise).  May be called repeatedly. */
 int kdip_unet_vjp(kdip_unet* u, void* stream, const float* cot_dev, int B, float* gx_dev);
 /* bytes of device workspace currently held for batch B (allocated lazily, grows monotonically). */
+long kdip_unet_workspace_bytes(kdip_unet* u, int B);
+/* Counter that changes whenever the handle re-allocates a workspace arena (a call at a batch whose plan does not fit): every
+ * device pointer a captured hipGraph of an earlier call baked in is dangling after that -- re-capture (kdip_amd/graphs.py). */
+long kdip_unet_workspace_generation(kdip_unet* u);
 /* Debug / test aid: 64-bit word sum of the activation stash kdip_unet_vjp reads (unchanged between a forward and its VJPs). */
 int kdip_unet_debug_stash_checksum(kdip_unet* u, void* stream, unsigned long long* sum_host);
-long kdip_unet_workspace_bytes(kdip_unet* u, int B);
 
 /* ------------------------------------------------- operators / solvers (rows A9-A13)
  * One context per measurement operator instance (condition/measurements.py:86-244). */

@@ -78,14 +78,18 @@ int kdip_unet_debug_stash_checksum(kdip_unet* u, void* stream, unsigned long lon
   KDIP_HIP_CHECK(hipSetDevice(u->u.device));
   unsigned long long* d = nullptr;
   KDIP_HIP_CHECK(hipMalloc((void**)&d, 8));
-  KDIP_HIP_CHECK(hipMemsetAsync(d, 0, 8, ST(stream)));
+  hipError_t e = hipMemsetAsync(d, 0, 8, ST(stream));
   const size_t n = u->u.persist.off / 4;
-  hipLaunchKernelGGL(checksum_kernel, dim3(2048), dim3(256), 0, ST(stream), (const unsigned*)u->u.persist.base, n, d);
-  KDIP_HIP_CHECK(hipMemcpyAsync(sum_host, d, 8, hipMemcpyDeviceToHost, ST(stream)));
-  KDIP_HIP_CHECK(hipStreamSynchronize(ST(stream)));
-  (void)hipFree(d);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(checksum_kernel, dim3(2048), dim3(256), 0, ST(stream), (const unsigned*)u->u.persist.base, n, d);
+    e = hipMemcpyAsync(sum_host, d, 8, hipMemcpyDeviceToHost, ST(stream));
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ST(stream));
+  (void)hipFree(d);                       // (freed on every path)
+  KDIP_HIP_CHECK(e);
   return KDIP_OK;
 }
+long kdip_unet_workspace_generation(kdip_unet* u) { return u ? u->u.ws_generation : -1; }
 long kdip_unet_workspace_bytes(kdip_unet* u, int B) {
   if (!u) return -1;
   if (B > 0 && u->u.finalized) { int rc = u->u.ensure_workspace(B); if (rc) return rc; }
@@ -259,11 +263,13 @@ int kdip_conv_create(int device, int dtype, const float* w_host, const float* bi
   c->dt = dtype == KDIP_BF16 ? DT_BF16 : DT_F32; c->cin = Cin; c->cout = Cout; c->cin_pad = pad32i(Cin); c->ntaps = ntaps; c->device = device;
   std::vector<char> buf(packed_weight_bytes(c->dt, ntaps, c->cin_pad, Cout));
   pack_conv_weight(c->dt, w_host, Cout, Cin, ntaps, 0, c->cin_pad, buf.data());
-  if (hipMalloc(&c->w, buf.size()) != hipSuccess) { delete c; return set_error(KDIP_ERR_NOMEM, "conv_create: hipMalloc failed"); }
-  KDIP_HIP_CHECK(hipMemcpy(c->w, buf.data(), buf.size(), hipMemcpyHostToDevice));
-  if (bias_host) {
-    KDIP_HIP_CHECK(hipMalloc((void**)&c->bias, sizeof(float) * Cout));
-    KDIP_HIP_CHECK(hipMemcpy(c->bias, bias_host, sizeof(float) * Cout, hipMemcpyHostToDevice));
+  bool ok = hipMalloc(&c->w, buf.size()) == hipSuccess && hipMemcpy(c->w, buf.data(), buf.size(), hipMemcpyHostToDevice) == hipSuccess;
+  if (ok && bias_host)
+    ok = hipMalloc((void**)&c->bias, sizeof(float) * Cout) == hipSuccess &&
+         hipMemcpy(c->bias, bias_host, sizeof(float) * Cout, hipMemcpyHostToDevice) == hipSuccess;
+  if (!ok) {                               // nothing of a half-built layer survives an error
+    kdip_conv_destroy(c);
+    return set_error(KDIP_ERR_NOMEM, "conv_create: device allocation / upload failed");
   }
   *out = c;
   return KDIP_OK;

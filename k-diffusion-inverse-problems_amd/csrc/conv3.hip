@@ -825,6 +825,11 @@ p.dbg = C3_TIMING ? g_c3_dbg : nullptr;
   KDIP_REQUIRE(stm == 0 || ((Cout >> 5) % 4 == 0 && p.st_sums), "conv3: fused statistics need Cout / 32 to be a multiple of 4");
   KDIP_REQUIRE(stm != 2 || (p.st_x && p.st_ldx % 8 == 0 && (uintptr_t)p.st_x % 16 == 0 && (uintptr_t)p.st_coef % 16 == 0 && (uintptr_t)p.st_mr % 8 == 0),
                "conv3: backward statistics need the GroupNorm input / coefficients (aligned)");
+  // (all launch preconditions are checked before prof_begin: an early return must not leave an unmatched event pair)
+  // instantiated combinations: forward convs (tf 0 / 1, statistics 0 / 1, with / without residual) and dgrad convs
+  // (tf 0 / 2, statistics 0 / 2, never a residual)
+  KDIP_REQUIRE(!(res && (tf == 2 || stm == 2)), "conv3: residual together with GroupNorm-backward fusion is not instantiated");
+  KDIP_REQUIRE(!(tf == 1 && stm == 2) && !(tf == 2 && stm == 1), "conv3: fusion mode combination is not instantiated");
   if (g_prof_on) {
     const double px = (double)B * H * W;
     const int cr = cin_real > 0 ? cin_real : Cin;
@@ -837,10 +842,6 @@ p.dbg = C3_TIMING ? g_c3_dbg : nullptr;
                          (stm == 2 ? px * Cout * 2.0 : 0.0);
     prof_begin(st, PC_CONV3_128x128, 2.0 * px * cr * Cout * 9, bytes, tags[tf][stm][res ? 1 : 0], B, H, cr, Cout);
   }
-  // instantiated combinations: forward convs (tf 0 / 1, statistics 0 / 1, with / without residual) and dgrad convs
-  // (tf 0 / 2, statistics 0 / 2, never a residual)
-  KDIP_REQUIRE(!(res && (tf == 2 || stm == 2)), "conv3: residual together with GroupNorm-backward fusion is not instantiated");
-  KDIP_REQUIRE(!(tf == 1 && stm == 2) && !(tf == 2 && stm == 1), "conv3: fusion mode combination is not instantiated");
   int rc;
 #define C3_GO(T, S, R) rc = launch3<T, S, R>(p, st)
   if (tf == 0 && stm == 0) { if (res) C3_GO(0, 0, true); else C3_GO(0, 0, false); }

@@ -76,6 +76,7 @@ struct UNet {
   float* sk_ws = nullptr; long sk_ws_floats = 0;   // split-K workspace of the small-spatial convs (zeros arena; kept zero by the finalize kernel)
   std::map<std::pair<const void*, int>, double*> fused_stats;   // (tensor, channels) -> GroupNorm sums already accumulated by its producer
   int ws_B = 0;                       // largest batch planned so far
+  long ws_generation = 0;             // bumped whenever an arena is re-allocated: captured hipGraphs hold raw arena pointers
   std::map<int, std::array<size_t, 3>> planned;   // batch -> (persist, scratch, zeros) peak bytes of a dry forward + VJP at that batch
   bool dry = false;
   // state of the last forward (for the VJP)

@@ -342,6 +342,7 @@ bool use_conv3(Ctx& c, const ConvW& w, int B, int H, int W, long ldx, long ldy, 
   if (!conv3_eligible(c.dt, w.ntaps, H, W, cin, cout, ldx, ldy)) return false;
   if ((long)B * (H / 8) * (W / 32) * (cout / 128) < KDIP_CONV3_MIN_BLOCKS) return false;
   if (tf && cin > conv3_tf_max_cin(tf)) return false;
+  if ((long)H * W * ldx * 2 >= (1L << 31)) return false;      // 32-bit staging offsets (conv3_forward's launch precondition): fall back to conv.hip
   // the GroupNorm-backward transform (two tensors, two fmas per element since the producer stores dz) is re-done by every
   // 128-channel output block
   if (tf == 2 && cout > KDIP_TF2_MAX_COUT) return false;
@@ -879,6 +880,7 @@ int UNet::ensure_workspace(int B) {
     a = Arena();
     if (hipMalloc((void**)&a.base, need) != hipSuccess) return set_error(KDIP_ERR_NOMEM, "workspace (%s): hipMalloc(%zu) failed", what, need);
     a.cap = need;
+    ++ws_generation;               // every pointer handed out from the old arena is dangling now (graphs.py re-captures)
     return KDIP_OK;
   };
   CK(grow(zeros, pk[2], "zeros"));

@@ -95,9 +95,8 @@ class OpenAIDenoiser(DiscreteEpsDDPMDenoiser):
         return res
 
     def loss(self, input, noise, sigma):
-        """The DWT-Var / DCT-Var objective (k_diffusion/external.py:145-159), evaluated forward-only (training itself is out of
-        scope): per sample  mean[(eps_hat - eps*)^2 / exp(logvar) + logvar] + the same in the transform basis with logvar_ot,
-        where eps* = (x - x_noised) / c_out = noise.  `sigma` [B]: samples that share a sigma share one UNet call."""
+        """eps-prediction objective inherited from DiscreteEpsDDPMDenoiser (k_diffusion/external.py:105-109), forward value:
+        per sample mean[(eps_hat(x + sigma*noise) - noise)^2].  `sigma` [B]: samples that share a sigma share one UNet call."""
         lib = L.load()
         B = input.shape[0]
         sig = sigma.detach().to("cpu", torch.float32).reshape(-1)
@@ -111,16 +110,13 @@ class OpenAIDenoiser(DiscreteEpsDDPMDenoiser):
             L.check(lib.kdip_axpby(L.stream(), L.ptr(x), 1.0, L.ptr(n), float(s), x.numel(), L.ptr(xn)))
             sv = x.new_full([len(idx)], float(s))
             sv._kdip_host_value = float(s)
-            model_output, logvar, logvar_ot = self.forward(xn, sv, return_variance=True)
-            model_output, logvar, logvar_ot = model_output.contiguous(), logvar.contiguous(), logvar_ot.contiguous()
-            # target = (input - noised_input) / c_out with c_out = -sigma  ==  noise (kept in the reference's form for the rounding)
-            target = torch.empty_like(x)
-            L.check(lib.kdip_axpby(L.stream(), L.ptr(x), -1.0 / float(s), L.ptr(xn), 1.0 / float(s), x.numel(), L.ptr(target)))
+            s32 = torch.tensor(float(s), dtype=torch.float32)
+            c_in = float(1 / (s32 ** 2 + 1) ** 0.5)
+            o, _, _ = self.inner_model.forward_raw(xn, self.sigma_to_t(sv), in_scale=c_in)
+            eps = (o[:, :3] if self.has_learned_sigmas else o).contiguous()
+            zero = torch.zeros_like(eps)              # unit variance: the NLL reduction kernel then returns mean (eps - noise)^2
             part = torch.empty(len(idx), device=input.device)
-            L.check(lib.kdip_gauss_nll_mean(L.stream(), L.ptr(model_output), L.ptr(target), L.ptr(logvar), len(idx), per, 0, L.ptr(part)))
-            ot = self.ortho_tf
-            mo_t, tg_t = ot(model_output).contiguous(), ot(target).contiguous()      # (named: raw pointers must outlive the call)
-            L.check(lib.kdip_gauss_nll_mean(L.stream(), L.ptr(mo_t), L.ptr(tg_t), L.ptr(logvar_ot), len(idx), per, 1, L.ptr(part)))
+            L.check(lib.kdip_gauss_nll_mean(L.stream(), L.ptr(eps), L.ptr(n), L.ptr(zero), len(idx), per, 0, L.ptr(part)))
             out[idx] = part
         return out
 

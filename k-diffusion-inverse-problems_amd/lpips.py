@@ -96,14 +96,26 @@ class LPIPS:
                 feats.append((cur, cout, h * w))
         return feats
 
+    @staticmethod
+    def check_size(H, W):
+        """The VGG feature pyramid runs on the conv kernels' tiles (four 2x2 max-pools down to >= 8x8 maps): power-of-two sizes
+        >= 128 only.  Callers that know their image size up front (sample_condition.py --lpips-checkpoint) call this BEFORE
+        sampling, so that an unsupported size fails at start-up instead of after the samples were paid for."""
+        if H < 128 or W < 128 or (H & (H - 1)) or (W & (W - 1)):
+            raise L.KdipError(f"LPIPS: image size {H}x{W} is not supported (power-of-two sizes >= 128 only)")
+
     def __call__(self, in0, in1, normalize=False):
         if not self._convs:
             raise L.KdipError("LPIPS: load_state_dict first (the pretrained weights are not bundled)")
         if in0.dim() == 3:
-            in0, in1 = in0[None], in1[None]
-        H, W = in0.shape[-2:]
-        if in0.shape != in1.shape or H < 128 or W < 128 or (H & (H - 1)) or (W & (W - 1)):
-            raise L.KdipError(f"LPIPS: images must have equal power-of-two sizes >= 128 (got {tuple(in0.shape)}, {tuple(in1.shape)})")
+            in0 = in0[None]
+        if in1.dim() == 3:
+            in1 = in1[None]
+        try:                                          # lpips.LPIPS broadcasts its two inputs (e.g. one reference against a batch)
+            in0, in1 = torch.broadcast_tensors(in0, in1)
+        except RuntimeError:
+            raise L.KdipError(f"LPIPS: input shapes {tuple(in0.shape)} and {tuple(in1.shape)} do not broadcast")
+        self.check_size(*in0.shape[-2:])
         in0 = in0.to(self.device, torch.float32)
         in1 = in1.to(self.device, torch.float32)
         if normalize:                                 # [0,1] -> [-1,1] (the package's flag; the reference leaves it off)

@@ -145,6 +145,10 @@ class UNetModel:
     def workspace_bytes(self, B):
         return int(self.lib.kdip_unet_workspace_bytes(self._h, B))
 
+    def workspace_generation(self):
+        """changes whenever the handle re-allocates its workspace arenas (captured hipGraphs of earlier calls are stale then)"""
+        return int(self.lib.kdip_unet_workspace_generation(self._h))
+
 
 def normalize_state_dict(obj, prefer_ema=True):
     """Checkpoint payload -> flat UNet `state_dict` in the reference key layout.

@@ -115,7 +115,8 @@ def main():
     p.add_argument("--synthetic-data", type=int, default=0, metavar="N", help="N seeded smooth images when the dataset folder is absent")
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--lpips-checkpoint", type=str, default="", help="state_dict of lpips.LPIPS(net='vgg') (VGG-16 backbone + lin layers); "
-                   "'synthetic' = seeded random weights (exercises the path, the value is meaningless); empty = no lpips key")
+                   "'synthetic' = seeded random weights (exercises the path, the value is meaningless); empty = no lpips key.  "
+                   "Needs a power-of-two image size >= 128 (checked at start-up)")
     p.add_argument("--cpu-rng", action="store_true", help="draw the measurement noise and x_T from torch's CPU generator (the random stream of "
                    "the reference's CPU path): a run is then comparable value for value with a run of the reference on the same seeds")
     p.add_argument("--streams", type=int, default=1, help="split each sampler batch into this many part-batches, each with its own "
@@ -190,6 +191,7 @@ def main():
     loss_fn_vgg = None
     if args.lpips_checkpoint:
         import kdip_amd.lpips as klp
+        klp.LPIPS.check_size(size[0], size[0])                 # fail at start-up, not after sampling, when the image size has no LPIPS path
         loss_fn_vgg = klp.LPIPS(net="vgg", device=device)
         loss_fn_vgg.load_state_dict(klp.synthetic_state_dict(args.seed) if args.lpips_checkpoint == "synthetic"
                                     else torch.load(args.lpips_checkpoint, map_location="cpu"))

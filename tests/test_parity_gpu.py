@@ -509,6 +509,32 @@ def test_dwtvar_loss_value(tiny, ortho):
     assert float((got - ref).abs().max() / ref.abs().max()) < 2e-4, (got, ref)
 
 
+@pytest.mark.gpu
+def test_eps_mse_loss_value(tiny):
+    """OpenAIDenoiser.loss = DiscreteEpsDDPMDenoiser.loss (k_diffusion/external.py:105-109): per-sample mean (eps_hat - noise)^2,
+    HIP path (f32 mode) against the formula on the oracle UNet, batch of 3 with two distinct sigmas."""
+    import kdip_amd.external as ke
+    from oracle import unet as ounet
+    from oracle.tables import DiffusionTables
+    models, D, sd, cfg = tiny
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand(3, 3, 64, 64, generator=g) * 2 - 1) * 0.7
+    noise = torch.randn(3, 3, 64, 64, generator=g)
+    sigma = torch.tensor([0.5, 2.0, 0.5])
+    den = ke.OpenAIDenoiser(models["f32"], D)
+    got = den.loss(x.cuda(), noise.cuda(), sigma.cuda()).cpu()
+    T_ = DiffusionTables()
+    ref = []
+    for i in range(3):
+        s = sigma[i:i + 1]
+        c_in = 1 / (s ** 2 + 1) ** 0.5
+        xn = x[i:i + 1] + noise[i:i + 1] * s
+        eps = ounet.unet_forward(sd, cfg, xn * c_in, T_.sigma_to_t(s)).chunk(2, dim=1)[0]
+        ref.append(float((eps - noise[i:i + 1]).pow(2).flatten(1).mean(1)))
+    ref = torch.tensor(ref)
+    assert float((got - ref).abs().max() / ref.abs().max()) < 2e-4, (got, ref)
+
+
 def test_hipgraph_capture_replay(gold, tiny):
     """Capture / replay of guided calls (kdip_amd.graphs.GraphedDenoiser): the closed-form branch is captured once per sigma into a
     hipGraph and replayed for new inputs with results equal to the eager call (fp64-atomic order noise only); the CG branch stays
@@ -532,3 +558,35 @@ def test_hipgraph_capture_replay(gold, tiny):
     lo = torch.tensor([0.12], device="cuda")                      # CG branch: eager
     o = gd(xs[0], lo)
     assert gd.eager_calls == 1 and float((o - den(xs[0], lo)).abs().max()) < 1e-4
+
+
+def test_hipgraph_invalidated_by_workspace_regrowth(gold):
+    """A call at a larger batch shape makes the UNet handle free + re-allocate its workspace arenas (unet.hip ensure_workspace): a
+    graph captured before that holds dangling pointers.  GraphedDenoiser records the handle's workspace generation and the
+    measurement tensors it captured against, drops its graphs when either changes, and re-captures on the next use."""
+    import kdip_amd.condition as kc
+    import kdip_amd.unet as ku
+    from kdip_amd.graphs import GraphedDenoiser
+    from oracle import unet as ounet
+    cfg = ounet.UNetConfig(**ounet.TINY)
+    sd = ounet.init_state_dict(cfg, seed=0)
+    m = ku.UNetModel(image_size=64, model_channels=32, num_res_blocks=1, attention_resolutions="32", channel_mult=(1, 2), dtype="f32", device="cuda")
+    m.load_state_dict(sd)                                 # a fresh handle: its arenas start empty and grow with the batch
+    D = ku.GaussianDiffusionTables()
+    hop, oop, (y, yf), x0 = make_ops("gaussian_blur", gold)
+    den = kc.ConditionOpenAIDenoiser(inner_model=m, diffusion=D, x0_cov_type="convert", recon_mse=None, operator=hop,
+                                     measurement=(y.cuda(), yf.cuda()), guidance="I", device="cuda")
+    gd = GraphedDenoiser(den)
+    g = torch.Generator().manual_seed(22)
+    x1 = (x0 + 1.5 * torch.randn(1, 3, 64, 64, generator=g)).cuda()
+    x4 = (x0 + 1.5 * torch.randn(4, 3, 64, 64, generator=g)).cuda()
+    s1, s4 = torch.tensor([1.5], device="cuda"), torch.full((4,), 1.5, device="cuda")
+    o1 = gd(x1, s1).clone()
+    gen0 = m.workspace_generation()
+    o4 = gd(x4, s4)                                       # larger batch: arenas regrown, the batch-1 graph is stale
+    assert m.workspace_generation() > gen0 and gd.invalidations >= 1
+    assert all(k[1][0] == 4 for k in gd._graphs)          # only graphs captured against the new arenas survive
+    o1b = gd(x1, s1)                                      # re-captured, not replayed from freed memory
+    assert float((o1b - o1).abs().max()) < 1e-4
+    assert float((o4 - den(x4, s4)).abs().max()) < 1e-4
+    assert float((gd(x1, s1) - den(x1, s1)).abs().max()) < 1e-4
