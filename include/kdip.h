@@ -209,6 +209,9 @@ int kdip_test_groupnorm(void* stream, int dtype, const float* x_nchw_dev, int B,
 int kdip_debug_conv_timing(void* dev_buf, int H, int cin, int cout, int st_mode);
 /* Same for csrc/conv3.hip (-DC3_TIMING=1): dev_buf[grid][8] = start, first patch staged, K loop done, end (100 MHz ticks), XCC id. */
 int kdip_debug_conv3_timing(void* dev_buf);
+/* Test / A-B aid: which bf16 3x3 kernel generation runs the large-map convs: 0 = automatic (conv4.hip where a launch has enough
+ * 16 x 32-pixel tiles to fill the chip, else conv3.hip), 3 = conv3.hip only, 4 = conv4.hip wherever the shape allows.  Process-wide. */
+int kdip_debug_conv_generation(int gen);
 
 #ifdef __cplusplus
 }

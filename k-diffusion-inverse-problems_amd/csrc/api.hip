@@ -381,6 +381,11 @@ int kdip_test_conv3(void* stream, const float* x_nchw, const float* x2_nchw, int
 }
 
 int kdip_debug_conv3_timing(void* dev_buf) { return conv3_debug_timing(dev_buf); }
+int kdip_debug_conv_generation(int gen) {
+  KDIP_REQUIRE(gen == 0 || gen == 3 || gen == 4, "conv generation must be 0 (automatic), 3 or 4");
+  conv_debug_generation(gen);
+  return KDIP_OK;
+}
 
 int kdip_test_groupnorm(void* stream, int dtype, const float* x_nchw, int B, int C, int H, int W, const float* gamma_host,
                         const float* beta_host, const float* film_host, int silu, float* y_nchw, const float* dy_nchw,

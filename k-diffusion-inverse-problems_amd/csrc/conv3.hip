@@ -26,6 +26,7 @@
 #include <type_traits>
 #include "common.h"
 #include "kernels.h"
+#include "conv3p.h"
 
 namespace kdip {
 
@@ -110,25 +111,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define C3_STRICT_LGKM 0       // 1: drain the LDS queue in front of every stage barrier (validation builds)
 #endif
 
-struct Conv3Params {
-  const bf16_t* x; long ldx;          // staged tensor (TF 0/1: the conv input or GroupNorm input; TF 2: dy of the GroupNorm output)
-  const bf16_t* x2; long ldx2;        // TF 2: the GroupNorm input
-  const uint4* wp;                    // packed weights (pack_conv_weight, bf16)
-  const float* bias;                  // [Cout] or null
-  const bf16_t* res; long ldr;        // residual or null
-  bf16_t* y; long ldy;
-  int B, H, W, Cin, Cout;
-  int ntilesN, tilesX, tilesY, mtiles, nblkN;
-  int in_ups, res_ups;
-  unsigned long long* dbg;            // C3_TIMING builds: [grid][8] stamps (start, first patch staged, K loop done, end) + XCC id
-  const float* tf_coef;               // TF 1: [B][Cin][2] (a, b); TF 2: [B][Cin][4] (a, b, k0, k1)
-  int tf_silu;
-  int st_silu;
-  double* st_sums;                    // [B][32][2]
-  const bf16_t* st_x; long st_ldx;    // mode 2: GroupNorm input of the produced gradient
-  const float* st_coef;               // mode 2: [B][Cout][2]
-  const float* st_mr;                 // mode 2: [B][32][2]
-};
 
 unsigned long long* g_c3_dbg = nullptr;
 #if C3_TIMING
@@ -840,9 +822,21 @@ p.dbg = C3_TIMING ? g_c3_dbg : nullptr;
     const double in_px = p.in_ups ? px / 4 : px, res_px = p.res_ups ? px / 4 : px;
     const double bytes = in_px * cr * 2.0 * (tf == 2 ? 2 : 1) + 9.0 * cr * Cout * 2.0 + px * Cout * 2.0 + (res ? res_px * Cout * 2.0 : 0.0) +
                          (stm == 2 ? px * Cout * 2.0 : 0.0);
-    prof_begin(st, PC_CONV3_128x128, 2.0 * px * cr * Cout * 9, bytes, tags[tf][stm][res ? 1 : 0], B, H, cr, Cout);
+    // (the profiler keeps the pointer: static storage) conv4[...]: the third-generation kernel (conv4.hip) runs this launch
+    static const char* tags4[3][3][2] = {{{"conv4", "conv4_res"}, {"conv4_s1", "conv4_s1_res"}, {"conv4_s2", "conv4_s2_res"}},
+                                         {{"conv4_gnf", "conv4_gnf_res"}, {"conv4_gnf_s1", "conv4_gnf_s1_res"}, {"conv4_gnf_s2", "conv4_gnf_s2_res"}},
+                                         {{"conv4_gnb", "conv4_gnb_res"}, {"conv4_gnb_s1", "conv4_gnb_s1_res"}, {"conv4_gnb_s2", "conv4_gnb_s2_res"}}};
+    const bool g4 = conv4_shape_ok(p) && Cin <= conv4_tf_max_cin(tf);
+    prof_begin(st, PC_CONV3_128x128, 2.0 * px * cr * Cout * 9, bytes, (g4 ? tags4 : tags)[tf][stm][res ? 1 : 0], B, H, cr, Cout);
   }
   int rc;
+  if (conv4_shape_ok(p) && Cin <= conv4_tf_max_cin(tf)) {      // third-generation kernel (conv4.hip) where the launch fills the chip with 512-pixel tiles
+    rc = conv4_launch(p, tf, stm, res != nullptr, st);
+    prof_end(st);
+    if (rc) return rc;
+    KDIP_LAUNCH_CHECK();
+    return KDIP_OK;
+  }
 #define C3_GO(T, S, R) rc = launch3<T, S, R>(p, st)
   if (tf == 0 && stm == 0) { if (res) C3_GO(0, 0, true); else C3_GO(0, 0, false); }
   else if (tf == 0 && stm == 1) { if (res) C3_GO(0, 1, true); else C3_GO(0, 1, false); }
