@@ -826,11 +826,11 @@ p.dbg = C3_TIMING ? g_c3_dbg : nullptr;
     static const char* tags4[3][3][2] = {{{"conv4", "conv4_res"}, {"conv4_s1", "conv4_s1_res"}, {"conv4_s2", "conv4_s2_res"}},
                                          {{"conv4_gnf", "conv4_gnf_res"}, {"conv4_gnf_s1", "conv4_gnf_s1_res"}, {"conv4_gnf_s2", "conv4_gnf_s2_res"}},
                                          {{"conv4_gnb", "conv4_gnb_res"}, {"conv4_gnb_s1", "conv4_gnb_s1_res"}, {"conv4_gnb_s2", "conv4_gnb_s2_res"}}};
-    const bool g4 = conv4_shape_ok(p) && Cin <= conv4_tf_max_cin(tf);
+    const bool g4 = conv4_shape_ok(p, tf, stm, res != nullptr) && Cin <= conv4_tf_max_cin(tf);
     prof_begin(st, PC_CONV3_128x128, 2.0 * px * cr * Cout * 9, bytes, (g4 ? tags4 : tags)[tf][stm][res ? 1 : 0], B, H, cr, Cout);
   }
   int rc;
-  if (conv4_shape_ok(p) && Cin <= conv4_tf_max_cin(tf)) {      // third-generation kernel (conv4.hip) where the launch fills the chip with 512-pixel tiles
+  if (conv4_shape_ok(p, tf, stm, res != nullptr) && Cin <= conv4_tf_max_cin(tf)) {      // third-generation kernel (conv4.hip) where the launch fills the chip with 512-pixel tiles
     rc = conv4_launch(p, tf, stm, res != nullptr, st);
     prof_end(st);
     if (rc) return rc;

@@ -22,11 +22,12 @@ struct Conv3Params {
   const bf16_t* st_x; long st_ldx;    // mode 2: GroupNorm input of the produced gradient
   const float* st_coef;               // mode 2: [B][Cout][2]
   const float* st_mr;                 // mode 2: [B][32][2]
+  unsigned mg_nblk, mg_tpi, mg_tx;    // conv4: ceil(2^32 / d) of nblkN, tilesX * tilesY, tilesX (0: d == 1) -- tile index -> coordinates without divisions
 };
 
 // conv4.hip: third-generation kernel (one 8-wave block per CU, 16 x 32-pixel x 128-channel tiles, two wave groups in ping-pong).
 // `p` is the block conv3_forward built (tile counts are recomputed for the 16-row tiles); returns KDIP_OK after the launch.
-bool conv4_shape_ok(const Conv3Params& p);
+bool conv4_shape_ok(const Conv3Params& p, int tf, int stm, bool res);
 int conv4_tf_max_cin(int tf);
 int conv4_launch(const Conv3Params& p, int tf, int stm, bool res, hipStream_t st);
 

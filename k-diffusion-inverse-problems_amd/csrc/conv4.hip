@@ -28,6 +28,7 @@
 //     transformed + written to the other patch buffer in phase i + 2.
 //   * the groups re-synchronise for the epilogue (one extra barrier each per tile) so that both store at the same time.
 #include <atomic>
+#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 #include "kernels.h"
@@ -42,11 +43,18 @@ constexpr int C4_PW = C4_TW + 2, C4_PH = C4_TH + 2, C4_NPIX = C4_PW * C4_PH;   /
 constexpr int C4_PIXB = 80;                               // LDS pixel pitch: 64 B of channels + 16 B pad (conflict-free ds_read_b128 of 32-pixel rows)
 constexpr int C4_ABUF = C4_NPIX * C4_PIXB;                // 48960 B per patch buffer
 constexpr int C4_BSLOT = 8192;                            // one weight stage: 2 k-steps x 4 n-tiles x 1 KiB
-constexpr int C4_NSLOT = 4;                               // weight ring: stage s + 2 is in flight while s and s + 1 are readable
+#ifndef C4_DDIST
+#define C4_DDIST 3             // weight DMA distance in phases: stage s + DDIST is requested in phase s
+#endif
+constexpr int C4_NSLOT = C4_DDIST + 2;                    // weight ring: the slot refilled in phase s was last read in phase s - 2
 constexpr int C4_MAXV = (C4_NPIX * 4 + C4_NTHR - 1) / C4_NTHR;   // staged 16-byte vectors per thread (5)
 constexpr int C4_LDS = 2 * C4_ABUF + C4_NSLOT * C4_BSLOT; // 130688 B: one block per CU
 constexpr int C4_MAXCOUT = 1024;                          // bias table in LDS (the accumulator init must not queue behind the previous tile's stores)
-constexpr int C4_LDS_TOTAL = C4_LDS + 64 + 1024 + 4 * C4_MAXCOUT;   // + dummy staging slot + statistics exchange [8 waves][2][16] floats + bias [Cout]
+#ifndef C4_TIMING
+#define C4_TIMING 0            // diagnostic build: s_memtime stamps of the first tile's phases (4 per phase) -> buffer set by conv4_debug_timing
+#endif
+constexpr int C4_NSTAMP = 176;
+constexpr int C4_LDS_TOTAL = C4_LDS + 64 + 1024 + 4 * C4_MAXCOUT + (C4_TIMING ? 8 * C4_NSTAMP * 8 : 0);   // + dummy staging slot + statistics exchange [8 waves][2][16] floats + bias [Cout]
 // per-channel coefficients of the staging transform ride in the 16-byte pads of the patch pixels (as in conv3): slot j = pad of
 // pixel j % 608 of buffer j / 608.  TF 1: slot = 2 channels x (a, b); TF 2: slot = 1 channel x (a, b, k0, k1), 608 = 19 x 32 so
 // a 32-channel chunk never straddles the buffers; within a chunk channel 8g + e sits in slot 4e + g (conflict-free, conv3.hip).
@@ -75,11 +83,41 @@ __device__ __forceinline__ int c4_tab_off(int slot) { return (slot / C4_TABPIX) 
 #ifndef C4_ABL_NOEPI
 #define C4_ABL_NOEPI 0
 #endif
+#ifndef C4_ABL_NOATOM
+#define C4_ABL_NOATOM 0        // epilogue ablations: no statistics atomics / no silu' transcendentals / no second input tensor / no output stores
+#endif
+#ifndef C4_ABL_NOSILU
+#define C4_ABL_NOSILU 0
+#endif
+#ifndef C4_ABL_NOAUX
+#define C4_ABL_NOAUX 0
+#endif
+#ifndef C4_ABL_NOSTORE
+#define C4_ABL_NOSTORE 0
+#endif
 #ifndef C4_ABL_NOMFMA
 #define C4_ABL_NOMFMA 0
 #endif
+#ifndef C4_SLEEP
+#define C4_SLEEP 0             // experiment: block j starts (j / 8 % 16) * C4_SLEEP * 64 cycles late (de-synchronises the chip-wide epilogue bursts)
+#endif
+#ifndef C4_TFINM
+#define C4_TFINM 1             // staging transform + LDS write between the MFMAs instead of in the load part (TF 1 / 2)
+#endif
+#ifndef C4_TFM_VALU
+#define C4_TFM_VALU 5
+#endif
+#ifndef C4_AUX_PREFETCH
+#define C4_AUX_PREFETCH 0     // measured: 197 -> 209 us (STM 2), 212 -> 222 us (RES): the touches queue HBM-latency loads in front of the counted weight DMAs
+#endif
+#ifndef C4_ONEBAR
+#define C4_ONEBAR 1            // one barrier per phase: group 0 runs (MFMA part, next load part) between barriers, group 1 (load part, MFMA part):
+#endif                         // the MFMA clusters of a SIMD's two waves alternate without a barrier hand-off between them
+#ifndef C4_CUNROLL
+#define C4_CUNROLL 2           // chunks per iteration of the chunk loop
+#endif
 #ifndef C4_MIN_TILES
-#define C4_MIN_TILES 192       // launches with fewer 512-pixel tiles stay on conv3's 256-pixel tiles (chip fill)
+#define C4_MIN_TILES 512       // launches with fewer than two 512-pixel tiles per CU stay on conv3's 256-pixel tiles (chip fill, first-tile prologue)
 #endif
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -107,6 +145,7 @@ __global__ __launch_bounds__(C4_NTHR, 2) void conv4_kernel(Conv3Params p) {
   const int nper = gridDim.x >> 3;
   int cur = xstart + (blockIdx.x >> 3);
   if (cur >= xend) return;
+  if (C4_SLEEP) { for (int i = (int)((blockIdx.x >> 3) & 15); i > 0; --i) __builtin_amdgcn_s_sleep(C4_SLEEP); }
   const int tpi = p.tilesX * p.tilesY;
   const int Hs = p.in_ups ? p.H >> 1 : p.H, Ws = p.in_ups ? p.W >> 1 : p.W;
   const int nchunks = p.Cin >> 5;
@@ -119,26 +158,33 @@ __global__ __launch_bounds__(C4_NTHR, 2) void conv4_kernel(Conv3Params p) {
   const bf16_t* ximg = p.x;
   const bf16_t* x2img = p.x;
   int tab_img = -1;
-  auto set_staging = [&](int bid) {
-    const int mtile = bid / p.nblkN;
-    const int im = mtile / tpi, trem = mtile - im * tpi;
-    const int ty = trem / p.tilesX;
-    const int yy = ty * C4_TH, xx = (trem - ty * p.tilesX) * C4_TW;
+  // tile-invariant part: halo coordinates of this thread's vectors (hy << 8 | hx), computed once; vectors outside the patch
+  // (pixel >= 612, only possible for the last vector) are flagged in zmask bits 8.. for the whole kernel
+  unsigned hyx[C4_MAXV];
+  unsigned zout = 0;
+#pragma unroll
+  for (int i = 0; i < C4_MAXV; ++i) {
+    const int pix = (tid + i * C4_NTHR) >> 2;
+    const int hy = pix / C4_PW, hx = pix - hy * C4_PW;
+    hyx[i] = (unsigned)(hy << 8 | hx);
+    if (pix >= C4_NPIX) zout |= 0x101u << i;
+  }
+  auto fdiv = [](unsigned n, unsigned magic) { return magic ? __umulhi(n, magic) : n; };      // n / d with magic = ceil(2^32 / d) (host), exact for n * d < 2^32
+  auto set_staging = [&](int bid) {                       // branch free, no divisions: it runs inside a load part
+    const int mtile = (int)fdiv((unsigned)bid, p.mg_nblk);
+    const int im = (int)fdiv((unsigned)mtile, p.mg_tpi), trem = mtile - im * tpi;
+    const int ty = (int)fdiv((unsigned)trem, p.mg_tx);
+    const int yy = ty * C4_TH - 1, xx = (trem - ty * p.tilesX) * C4_TW - 1;
     ximg = p.x + (long)im * Hs * Ws * p.ldx;
     if (TF == 2) x2img = p.x2 + (long)im * Hs * Ws * p.ldx;
-    zmask = 0;
+    zmask = zout;
 #pragma unroll
     for (int i = 0; i < C4_MAXV; ++i) {
-      const int v = tid + i * C4_NTHR, pix = v >> 2;
-      const int hy = pix / C4_PW, hx = pix - hy * C4_PW;
-      const int gy = yy + hy - 1, gx = xx + hx - 1;
-      goff[i] = (unsigned)((tid & 3) * 16);
-      if (pix >= C4_NPIX) zmask |= 0x101u << i;
-      else if (gy < 0 || gy >= p.H || gx < 0 || gx >= p.W) zmask |= 1u << i;
-      else {
-        const int spix = p.in_ups ? (gy >> 1) * Ws + (gx >> 1) : gy * Ws + gx;
-        goff[i] = (unsigned)((spix * (int)p.ldx + (tid & 3) * 8) * 2);
-      }
+      const int gy = yy + (int)(hyx[i] >> 8), gx = xx + (int)(hyx[i] & 255);
+      const bool inimg = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W && !((zout >> i) & 1);
+      const int spix = p.in_ups ? (gy >> 1) * Ws + (gx >> 1) : gy * Ws + gx;
+      goff[i] = inimg ? (unsigned)((spix * (int)p.ldx + (tid & 3) * 8) * 2) : (unsigned)((tid & 3) * 16);
+      zmask |= (inimg ? 0u : 1u) << i;
     }
     return im;
   };
@@ -156,6 +202,12 @@ __global__ __launch_bounds__(C4_NTHR, 2) void conv4_kernel(Conv3Params p) {
   // ---- staging loads are inline asm: hipcc must neither wait for them itself (next to LDS-DMA traffic it drains the whole
   // queue) nor touch their destination registers before the counted wait of the phase that consumes them
   constexpr int NV = TF == 2 ? 2 : 1;                     // staging loads per vector
+  // The epilogue reads a second tensor (residual / GroupNorm input of the produced gradient): 64 KB per tile whose HBM latency --
+  // of every CU at the same moment -- would sit exposed behind the last MFMA (measured: 28 - 36 us of a 205 - 215 us launch).  Taps
+  // 5 .. 8 of every chunk (no staging loads there) touch the four 128-byte lines of this thread's tile pixels, so the epilogue's
+  // loads are served by L2.  Results are discarded; the loads are counted like the others.
+  constexpr bool AUXPF = C4_AUX_PREFETCH && (RES || STM == 2);
+  unsigned pf = 0;
   u32x4 sa[2], sb[2];
   auto vec_load_asm = [&](int cbytes, int i) {          // chunk byte offset (chunk * 64), vector i -> register set i & 1
     const unsigned off = goff[i] + (unsigned)cbytes;
@@ -210,21 +262,30 @@ __global__ __launch_bounds__(C4_NTHR, 2) void conv4_kernel(Conv3Params p) {
                  : "=&s"(keep) : "v"(w_voff), "s"(g), "s"(l) : "memory");
   };
 
+  auto ring = [](int x) {      // x % NSLOT for x < 4 NSLOT, wave-uniform (kept in SGPRs: it feeds M0)
+    return __builtin_amdgcn_readfirstlane(C4_NSLOT == 4 ? (x & 3) : x - C4_NSLOT * ((x >= C4_NSLOT ? 1 : 0) + (x >= 2 * C4_NSLOT ? 1 : 0) + (x >= 3 * C4_NSLOT ? 1 : 0)));
+  };
   const int a_lane = (wm * 4 * C4_PW + (lane & 31)) * C4_PIXB + (lane >> 5) * 16;   // + (mt + ty) * PW * PIXB + tx * PIXB + ks * 32
   const int b_lane = 2 * C4_ABUF + (wn * 2 * 64 + lane) * 16;                       // + slot * BSLOT + (ks * 4 + nt) * 1024
   const int cpg = p.Cout >> 5;
   float* const sbias = (float*)(smem + C4_LDS + 64 + 1024);
+#if C4_TIMING
+  unsigned long long* const tl = (unsigned long long*)(smem + C4_LDS + 64 + 1024 + 4 * C4_MAXCOUT) + wave * C4_NSTAMP;
+  bool tfirst = true;
+  int tcount = 0;
+  if (lane == 0) { tl[170] = __builtin_readcyclecounter(); tl[171] = __builtin_amdgcn_s_memrealtime(); }
+#define C4_STAMP(k) do { if (C4_TIMING >= 2 && tfirst && c * 9 + tap < 36) { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) tl[(c * 9 + tap) * 4 + (k)] = t_; } } while (0)
+#else
+#define C4_STAMP(k) do { } while (0)
+#endif
 
   // ---- prologue of the block's FIRST tile: weight stages 0 and 1, coefficient table, the whole first patch
   {
-    const int nb0 = cur % p.nblkN;
-    dma_w(nb0, 0, 0, 0);
-    dma_w(nb0, 0, 1, 1);
+    const int nb0 = cur - (int)fdiv((unsigned)cur, p.mg_nblk) * p.nblkN;
+#pragma unroll
+    for (int t = 0; t < C4_DDIST; ++t) dma_w(nb0, 0, t, t);
     const int im = set_staging(cur);
-    if (TF) load_table(im);
-    for (int j = tid; j < p.Cout; j += C4_NTHR) sbias[j] = p.bias ? p.bias[j] : 0.f;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    // every global load of the prologue is requested before the first wait (one HBM round trip instead of three)
     uint4 o[C4_MAXV], o2[C4_MAXV];
 #pragma unroll
     for (int i = 0; i < C4_MAXV; ++i) {
@@ -232,6 +293,10 @@ __global__ __launch_bounds__(C4_NTHR, 2) void conv4_kernel(Conv3Params p) {
       o2[i] = make_uint4(0, 0, 0, 0);
       if (TF == 2) o2[i] = *(const uint4*)((const char*)x2img + goff[i]);
     }
+    if (TF) load_table(im);
+    for (int j = tid; j < p.Cout; j += C4_NTHR) sbias[j] = p.bias ? p.bias[j] : 0.f;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                          // coefficient table visible to every wave
 #pragma unroll
     for (int i = 0; i < C4_MAXV; ++i) vec_store(0, i, transform(0, i, o[i], o2[i]));
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -242,19 +307,35 @@ __global__ __launch_bounds__(C4_NTHR, 2) void conv4_kernel(Conv3Params p) {
 
   for (;;) {
     // ---- current tile
-    const int mtile = cur / p.nblkN, nb = cur - mtile * p.nblkN;
-    const int img = mtile / tpi, trem = mtile - img * tpi;
-    const int ty0 = trem / p.tilesX;
+    const int mtile = (int)fdiv((unsigned)cur, p.mg_nblk), nb = cur - mtile * p.nblkN;
+    const int img = (int)fdiv((unsigned)mtile, p.mg_tpi), trem = mtile - img * tpi;
+    const int ty0 = (int)fdiv((unsigned)trem, p.mg_tx);
     const int y0 = ty0 * C4_TH, x0 = (trem - ty0 * p.tilesX) * C4_TW;
     const int nxt = cur + nper;
     const bool has_next = nxt < xend;
-    const int nb_n = has_next ? nxt % p.nblkN : nb;
+    const int nb_n = has_next ? nxt - (int)fdiv((unsigned)nxt, p.mg_nblk) * p.nblkN : nb;
 
     // accumulators start at the bias (lane (pixel, h) owns channels nt*32 + 8q + 4h + j in registers 4q + j)
     int tv = threadIdx.x;
     asm volatile("" : "+v"(tv));        // (opaque copy: lane-derived values must not be hoisted out of the tile loop and kept live)
 #pragma unroll
     for (int j = 0; j < 2; ++j) { sa[j] = (u32x4){0, 0, 0, 0}; sb[j] = (u32x4){0, 0, 0, 0}; }
+    const bf16_t* aux_img = p.y;      // wave-uniform row base of the tensor the epilogue reads + this thread's pixel offset, row stride
+    unsigned aux_off = 0, aux_rs = 0;
+    if (AUXPF) {
+      const int px = x0 + (tv & 31), r0 = y0 + wm * 4;
+      if (RES) {
+        const int Hr = p.res_ups ? p.H >> 1 : p.H, Wr = p.res_ups ? p.W >> 1 : p.W;
+        aux_img = p.res + ((long)img * Hr + (p.res_ups ? r0 >> 1 : r0)) * Wr * p.ldr + nb * C4_BN + wn * 64;
+        aux_off = (unsigned)((p.res_ups ? px >> 1 : px) * (int)p.ldr * 2);
+        aux_rs = (unsigned)(Wr * (int)p.ldr * 2);      // (res_ups: rows r0 .. r0 + 3 are two source rows: lines mt >> 1)
+      } else {
+        aux_img = p.st_x + ((long)img * p.H + r0) * p.W * p.st_ldx + nb * C4_BN + wn * 64;
+        aux_off = (unsigned)(px * (int)p.st_ldx * 2);
+        aux_rs = (unsigned)(p.W * (int)p.st_ldx * 2);
+      }
+    }
+    pf = 0;
     f32x16 acc[4][2];
     {
       const int h = (tv >> 5) & 1;
@@ -270,7 +351,7 @@ __global__ __launch_bounds__(C4_NTHR, 2) void conv4_kernel(Conv3Params p) {
         }
     }
     // from here to the epilogue every VMEM operation is counted by hand
-    if (grp) __builtin_amdgcn_s_barrier();               // group 1 runs one barrier behind group 0 until the end of the K loop
+    if (!C4_ONEBAR && grp) __builtin_amdgcn_s_barrier();               // group 1 runs one barrier behind group 0 until the end of the K loop
 
     // Per phase (chunk c, tap t) every wave issues, in this order: 12 fragment reads, the weight DMA of stage s + 2, the counted
     // wait, the transform + LDS write of staging vector t - 2, the staging load(s) of vector t.  The wait must cover the DMA of
@@ -279,8 +360,11 @@ __global__ __launch_bounds__(C4_NTHR, 2) void conv4_kernel(Conv3Params p) {
     //   -> vmcnt(1 + nv(t - 1)), nv(t) = NV for t < 5 else 0 (taps wrap within the 9-tap chunk).
     // Phase 0 of a tile's first chunk needs nothing new (stage 1 was confirmed in front of the previous epilogue / by the
     // prologue) and does not wait: the previous epilogue's output stores stay in flight under the first phase.
-#define C4_NVT(t) (((t) + 9) % 9 < C4_MAXV ? NV : 0)
-    for (int c = 0; c < nchunks; ++c) {
+#define C4_NVT(t) (((t) + 9) % 9 < C4_MAXV ? NV : (AUXPF && ((t) + 9) % 9 < C4_MAXV + 4 ? 1 : 0))
+#if C4_TIMING
+    if (lane == 0 && tcount < 8) tl[145 + 3 * tcount] = __builtin_readcyclecounter();          // K loop start
+#endif
+    auto chunk = [&](int c) __attribute__((always_inline)) {
       const bool last = c + 1 == nchunks;
       if (last && has_next) {                            // from here on the staging loads belong to the next tile
         const int im = set_staging(nxt);
@@ -298,7 +382,8 @@ __global__ __launch_bounds__(C4_NTHR, 2) void conv4_kernel(Conv3Params p) {
       auto phase = [&](auto tapc) {
         constexpr int tap = decltype(tapc)::value;
         // ---- load part
-        const unsigned char* bb = smem + b_lane + ((sidx + tap) & 3) * C4_BSLOT;
+        C4_STAMP(0);
+        const unsigned char* bb = smem + b_lane + ring(sidx + tap) * C4_BSLOT;
         constexpr int toff = ((tap / 3) * C4_PW + (tap % 3)) * C4_PIXB;
         uint4 xa[2][4], wb[2][2];
         if (C4_ABL_NOLDSR) {
@@ -317,27 +402,47 @@ __global__ __launch_bounds__(C4_NTHR, 2) void conv4_kernel(Conv3Params p) {
           for (int mt = 0; mt < 4; ++mt) xa[ks][mt] = *(const uint4*)(ab + mt * C4_PW * C4_PIXB + toff + ks * 32);
         }
         if (!C4_ABL_NODMA) {
-          constexpr int t2 = tap + 2 >= 9 ? tap + 2 - 9 : tap + 2;
-          if (tap + 2 >= 9) dma_w(wnb, wc, t2, (sidx + tap + 2) & 3); else dma_w(nb, c, t2, (sidx + tap + 2) & 3);
+          constexpr int t2 = tap + C4_DDIST >= 9 ? tap + C4_DDIST - 9 : tap + C4_DDIST;
+          if (tap + C4_DDIST >= 9) dma_w(wnb, wc, t2, ring(sidx + tap + C4_DDIST)); else dma_w(nb, c, t2, ring(sidx + tap + C4_DDIST));
         }
-        constexpr int NW = 1 + C4_NVT(tap - 1);
-        if (!C4_ABL_NOWAIT && (tap != 0 || c > 0)) {
-          if (TF == 2) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sb[0]), "+v"(sb[1]) : "n"(NW) : "memory");
-          else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(sa[0]), "+v"(sa[1]) : "n"(NW) : "memory");
+        // counted wait: the DMA of stage s + 1 (requested in phase s + 1 - DDIST) and, in the phases that write one, staging vector
+        // t - 2 (requested at the end of phase s - 2) must have landed; everything requested later may stay in flight
+        constexpr bool WR = tap >= 2 && tap < 2 + C4_MAXV;
+        constexpr int NW = C4_DDIST == 2 ? 1 + C4_NVT(tap - 1) : (WR ? 2 + C4_NVT(tap - 1) : 2 + C4_NVT(tap - 2) + C4_NVT(tap - 1));
+        if (!C4_ABL_NOWAIT && (tap >= C4_DDIST - 1 || c > 0)) {
+          if (TF == 2) asm volatile("s_waitcnt vmcnt(%5)" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sb[0]), "+v"(sb[1]), "+v"(pf) : "n"(NW) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%3)" : "+v"(sa[0]), "+v"(sa[1]), "+v"(pf) : "n"(NW) : "memory");
         }
-        if (!C4_ABL_NOSTG && tap >= 2 && tap < 2 + C4_MAXV) {
-          constexpr int i = tap >= 2 ? tap - 2 : 0;
-          const uint4 o = __builtin_bit_cast(uint4, sa[i & 1]);
-          const uint4 o2 = TF == 2 ? __builtin_bit_cast(uint4, sb[i & 1]) : make_uint4(0, 0, 0, 0);
-          vec_store(nbuf, i, transform(cn, i, o, o2));
+        // the staging transform (GroupNorm apply: ~60 VALU per vector for TF 1) would make the load part longer than the partner's
+        // MFMA part: with TFM it is issued between this wave's own MFMAs instead (<= 4 VALU per MFMA gap), and the next staging
+        // load (same register set) follows the MFMAs
+        constexpr bool TFM = C4_TFINM && TF != 0;
+        auto stage_write = [&]() {
+          if (!C4_ABL_NOSTG && tap >= 2 && tap < 2 + C4_MAXV) {
+            constexpr int i = tap >= 2 ? tap - 2 : 0;
+            const uint4 o = __builtin_bit_cast(uint4, sa[i & 1]);
+            const uint4 o2 = TF == 2 ? __builtin_bit_cast(uint4, sb[i & 1]) : make_uint4(0, 0, 0, 0);
+            vec_store(nbuf, i, transform(cn, i, o, o2));
+          }
+        };
+#define C4_AUX_TOUCH() do { if (AUXPF && tap >= C4_MAXV && tap < C4_MAXV + 4) { \
+            constexpr int mt_ = tap >= C4_MAXV ? tap - C4_MAXV : 0; \
+            const unsigned off_ = aux_off + (unsigned)((RES && p.res_ups) ? mt_ >> 1 : mt_) * aux_rs; \
+            asm volatile("global_load_dword %0, %1, %2" : "=v"(pf) : "v"(off_), "s"(aux_img) : "memory"); } } while (0)
+        if (!TFM) {
+          stage_write();
+          if (!C4_ABL_NOSTG && tap < C4_MAXV) vec_load_asm(cn * 64, tap);
+          C4_AUX_TOUCH();
         }
-        if (!C4_ABL_NOSTG && tap < C4_MAXV) vec_load_asm(cn * 64, tap);
         // ---- MFMA part, between two barriers
+        C4_STAMP(1);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        if (!C4_ONEBAR || !grp) __builtin_amdgcn_s_barrier();       // (one barrier per phase: group 0 here, group 1 behind its MFMAs)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        C4_STAMP(2);
         if (C4_PRIO) __builtin_amdgcn_s_setprio(C4_PRIO);
+        if (TFM) stage_write();
         if (C4_ABL_NOMFMA) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) acc[i & 3][i >> 2][tap] += __uint_as_float((&xa[0][0])[i].x ^ (&wb[0][0])[i & 3].y);
@@ -349,22 +454,53 @@ __global__ __launch_bounds__(C4_NTHR, 2) void conv4_kernel(Conv3Params p) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma_bf16(wb[ks][nt], xa[ks][mt], acc[mt][nt]);
         }
+        if (TFM && WR) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x006, C4_TFM_VALU, 0);     // then up to C4_TFM_VALU VALU / SALU
+          }
+        }
         if (C4_PRIO) __builtin_amdgcn_s_setprio(0);
+        if (TFM && !C4_ABL_NOSTG && tap < C4_MAXV) vec_load_asm(cn * 64, tap);
+        if (TFM) C4_AUX_TOUCH();
+        C4_STAMP(3);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        if (!C4_ONEBAR || grp) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
       };
       phase(std::integral_constant<int, 0>{}); phase(std::integral_constant<int, 1>{}); phase(std::integral_constant<int, 2>{});
       phase(std::integral_constant<int, 3>{}); phase(std::integral_constant<int, 4>{}); phase(std::integral_constant<int, 5>{});
       phase(std::integral_constant<int, 6>{}); phase(std::integral_constant<int, 7>{}); phase(std::integral_constant<int, 8>{});
-      sidx = (sidx + 1) & 3;                             // 9 stages per chunk
+      sidx = ring(sidx + 9);                             // 9 stages per chunk
+    };
+#if C4_CUNROLL == 1
+    for (int c = 0; c < nchunks; ++c) chunk(c);
+#else
+    // the chunk loop's taken back-edge stalls a wave for 1 - 2 k cycles (measured with the C4_TIMING stamps: instruction fetch
+    // of the branch target while the partner wave streams MFMAs); C4_CUNROLL chunks per iteration run as straight-line code
+    for (int c = 0; c < nchunks; c += C4_CUNROLL) {
+      chunk(c);
+#pragma unroll
+      for (int u = 1; u < C4_CUNROLL; ++u)
+        if (c + u < nchunks) chunk(c + u);
     }
+#endif
 #undef C4_NVT
-    if (C4_STAGGER && !grp) __builtin_amdgcn_s_barrier();   // re-synchronise the groups: both run the epilogue at the same time
+#if C4_TIMING
+    if (lane == 0 && tcount < 8) tl[146 + 3 * tcount] = __builtin_readcyclecounter();          // K loop done
+    if (C4_TIMING >= 2 && tfirst && p.dbg) {
+      tl[144] = __builtin_readcyclecounter();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      for (int i = lane; i < C4_NSTAMP; i += 64) p.dbg[((long)blockIdx.x * 8 + wave) * C4_NSTAMP + i] = tl[i];
+    }
+    tfirst = false;
+#endif
+    if (!C4_ONEBAR && C4_STAGGER && !grp) __builtin_amdgcn_s_barrier();   // re-synchronise the groups: both run the epilogue at the same time
     pb = (pb + nchunks) & 1;
     // everything the K loop issued (the next tile's stage-1 weights were requested one phase ago) is confirmed here, so that
     // the next tile's first phase does not have to wait behind this epilogue's stores
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf) :: "memory");
 
     if (C4_ABL_NOEPI) {     // timing ablation: keep the accumulators live, skip the epilogue
       float t = 0.f;
@@ -399,7 +535,7 @@ __global__ __launch_bounds__(C4_NTHR, 2) void conv4_kernel(Conv3Params p) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-          for (int k = 0; k < 2; ++k) aux[mt][nt][k] = *(const uint4*)(r + (nt * 32 + 16 * k) * 2);
+          for (int k = 0; k < 2; ++k) aux[mt][nt][k] = C4_ABL_NOAUX ? make_uint4(te, mt, nt, k) : *(const uint4*)(r + (nt * 32 + 16 * k) * 2);
       }
     } else if (STM == 2) {
       const char* const xb = (const char*)(p.st_x + ((long)img * p.H + row0) * p.W * p.st_ldx + nbase);
@@ -409,8 +545,12 @@ __global__ __launch_bounds__(C4_NTHR, 2) void conv4_kernel(Conv3Params p) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-          for (int k = 0; k < 2; ++k) aux[mt][nt][k] = *(const uint4*)(xb + mt * rsx + lane_x + (nt * 32 + 16 * k) * 2);
+          for (int k = 0; k < 2; ++k) aux[mt][nt][k] = C4_ABL_NOAUX ? make_uint4(te, mt, nt, k) : *(const uint4*)(xb + mt * rsx + lane_x + (nt * 32 + 16 * k) * 2);
     }
+
+#if C4_TIMING
+    if (tcount == 1 && lane == 0) tl[160 + 0] = __builtin_readcyclecounter();
+#endif
     float ss[16];                                           // [0..7]: sum 1 per channel quad, [8..15]: sum 2
 #pragma unroll
     for (int i = 0; i < 16; ++i) ss[i] = 0.f;
@@ -450,7 +590,7 @@ __global__ __launch_bounds__(C4_NTHR, 2) void conv4_kernel(Conv3Params p) {
       }
       const uint4 o = make_uint4(w0x, w0y, w1x, w1y);
       if (STM == 2) wst[STM == 2 ? mt : 0][nt][k] = o;        // turned into dz and stored by sweep 2
-      else *(uint4*)(yb + mt * rsy + coff + lane_y) = o;
+      else if (!C4_ABL_NOSTORE || o.x == 0x12345678u) *(uint4*)(yb + mt * rsy + coff + lane_y) = o;
     };
     // pixel-row-major item order: the four 16-byte vectors of a pixel (this wave's 64 channels = one 128-byte run) are stored
     // back to back so that L2 merges them into whole lines
@@ -469,6 +609,10 @@ __global__ __launch_bounds__(C4_NTHR, 2) void conv4_kernel(Conv3Params p) {
           ss[nt * 4 + 2 * k + 1] = t1v[nt][k][1][0] + t1v[nt][k][1][1]; ss[8 + nt * 4 + 2 * k + 1] = t2v[nt][k][1][0] + t2v[nt][k][1][1];
         }
     }
+
+#if C4_TIMING
+    if (tcount == 1 && lane == 0) tl[160 + 1] = __builtin_readcyclecounter();
+#endif
     // ---- sweep 2 (backward statistics), in the STORE layout: this lane's vector (nt, k) = channels nt*32 + 16k + 8h .. +7 of
     // its pixel, from the stored (rounded) dy and the GroupNorm input.  Quad index nt*4 + 2k (+1) = channels nt*32 + 16k + 8h (+4) .. +3
     if (STM == 2) {
@@ -491,7 +635,7 @@ __global__ __launch_bounds__(C4_NTHR, 2) void conv4_kernel(Conv3Params p) {
               const float4 kk = ka[e >> 1];
               const float a = (e & 1) ? kk.z : kk.x, b = (e & 1) ? kk.w : kk.y;
               const float z = a * xg[e] + b;
-              dzv[e] = dy[e] * silu_grad_fast(z);
+              dzv[e] = dy[e] * (C4_ABL_NOSILU ? z : silu_grad_fast(z));
               const float adz = a * dzv[e];
               t1[e >> 2] += adz;
               t2[e >> 2] += adz * xg[e];
@@ -507,14 +651,22 @@ __global__ __launch_bounds__(C4_NTHR, 2) void conv4_kernel(Conv3Params p) {
           }
         }
       }
+
+#if C4_TIMING
+    if (tcount == 1 && lane == 0) tl[160 + 2] = __builtin_readcyclecounter();
+#endif
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
           for (int k = 0; k < 2; ++k)
-            *(uint4*)(yb + mt * rsy + (unsigned)((nt * 32 + 16 * k) * 2) + lane_y) = wst[STM == 2 ? mt : 0][nt][k];
+            if (!C4_ABL_NOSTORE || wst[STM == 2 ? mt : 0][nt][k].x == 0x12345678u) *(uint4*)(yb + mt * rsy + (unsigned)((nt * 32 + 16 * k) * 2) + lane_y) = wst[STM == 2 ? mt : 0][nt][k];
     }
+#if C4_TIMING
+    if (tcount == 1 && lane == 0) tl[160 + 3] = __builtin_readcyclecounter();
+#endif
+
     if (STM) {
       // 16 partial sums per lane, 32 pixel lanes per half-wave: butterfly reduce-scatter (8 + 4 + 2 + 1 exchanges, then one
       // plain exchange) leaves value j = bits (4,3,2,1) of the lane index, summed over the half-wave, in every lane
@@ -544,16 +696,28 @@ __global__ __launch_bounds__(C4_NTHR, 2) void conv4_kernel(Conv3Params p) {
         for (int w4 = 0; w4 < 4; ++w4) a += sred[((w4 * 2 + wn2) * 2 + h2) * 16 + j];
         const int i = j & 7;          // quad (nt = i >> 2, 2k + q = i & 3): accumulator layout (mode 1) or store layout (mode 2)
         const int ch = nb * C4_BN + wn2 * 64 + (i >> 2) * 32 + (STM == 2 ? ((i >> 1) & 1) * 16 + 8 * h2 + (i & 1) * 4 : (i & 3) * 8 + 4 * h2);
-        atomicAdd(p.st_sums + ((long)img * 32 + ch / cpg) * 2 + (j >> 3), (double)a);
+        if (C4_ABL_NOATOM) { if (a == 12345.678f) p.st_sums[0] = a; }
+        else atomicAdd(p.st_sums + ((long)img * 32 + ch / cpg) * 2 + (j >> 3), (double)a);
       }
       // (sred is rewritten by the next tile's epilogue only after a full K loop of barriers)
     }
     }
+#if C4_TIMING
+    if (lane == 0 && tcount < 8) tl[147 + 3 * tcount] = __builtin_readcyclecounter();          // epilogue done (stores issued)
+    ++tcount;
+#endif
     if (!has_next) break;
     cur = nxt;
   }
   // drain the redundant tail loads / DMAs before the wave ends
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#if C4_TIMING
+  if (p.dbg) {
+    if (lane == 0) { tl[172] = __builtin_readcyclecounter(); tl[173] = __builtin_amdgcn_s_memrealtime(); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int i = 145 + lane; i < C4_NSTAMP; i += 64) p.dbg[((long)blockIdx.x * 8 + wave) * C4_NSTAMP + i] = tl[i];
+  }
+#endif
 }
 
 template <int TF, int STM, bool RES>
@@ -580,15 +744,27 @@ int launch4(const Conv3Params& p, hipStream_t st) {
   return KDIP_OK;
 }
 
-std::atomic<int> g_conv_gen{0};     // 0: automatic choice, 3 / 4: force the second- / third-generation kernel where the shape allows
+unsigned long long* g_c4_dbg = nullptr;
+// 0: automatic choice, 3 / 4: force the second- / third-generation kernel where the shape allows (initial value: KDIP_CONV_GEN)
+std::atomic<int> g_conv_gen{[] { const char* e = getenv("KDIP_CONV_GEN"); const int v = e ? atoi(e) : 0; return v == 3 || v == 4 ? v : 0; }()};
 
 }  // namespace
 
 void conv_debug_generation(int gen) { g_conv_gen.store(gen); }
+int conv4_debug_timing(void* buf) {
+  if (!C4_TIMING) return set_error(KDIP_ERR_UNSUPPORTED, "conv4 timing: library not built with -DC4_TIMING=1");
+  g_c4_dbg = (unsigned long long*)buf;
+  return KDIP_OK;
+}
 int conv4_tf_max_cin(int tf) { return c4_max_cin(tf); }
 
-bool conv4_shape_ok(const Conv3Params& p) {
+// tf / stm / res: fusion mode of the launch.  Automatic choice (measured against conv3, tools/conv4_micro.py, 8 and 16 images of
+// 128 -> 128 and 256 -> 128 @ 256^2): the ping-pong K loop wins where the epilogue is light -- plain / forward-statistics
+// epilogues without a residual (-3 ... -6 %) --; with a residual or the GroupNorm-backward epilogue / staging the block-wide
+// epilogue (nothing overlaps it: both wave groups reach it together) gives the gain back (+0 ... +5 %), those stay on conv3.
+bool conv4_shape_ok(const Conv3Params& p, int tf, int stm, bool res) {
   if (g_conv_gen.load() == 3) return false;
+  if (g_conv_gen.load() == 0 && (res || stm == 2 || tf == 2)) return false;
   if (p.H % C4_TH != 0 || p.W % C4_TW != 0 || p.Cout % C4_BN != 0 || p.Cin % 32 != 0 || p.Cout > C4_MAXCOUT) return false;
   const long tiles = (long)p.B * (p.H / C4_TH) * (p.W / C4_TW) * (p.Cout / C4_BN);
   return g_conv_gen.load() == 4 || tiles >= C4_MIN_TILES;
@@ -596,7 +772,11 @@ bool conv4_shape_ok(const Conv3Params& p) {
 
 int conv4_launch(const Conv3Params& p0, int tf, int stm, bool res, hipStream_t st) {
   Conv3Params p = p0;
+  p.dbg = C4_TIMING ? g_c4_dbg : nullptr;
   p.tilesX = p.W / C4_TW; p.tilesY = p.H / C4_TH; p.mtiles = p.B * p.tilesX * p.tilesY; p.nblkN = p.Cout / C4_BN;
+  auto magic = [](unsigned d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); };
+  p.mg_nblk = magic((unsigned)p.nblkN); p.mg_tpi = magic((unsigned)(p.tilesX * p.tilesY)); p.mg_tx = magic((unsigned)p.tilesX);
+  KDIP_REQUIRE((long)p.mtiles * p.nblkN * (long)(p.tilesX * p.tilesY > p.nblkN ? p.tilesX * p.tilesY : p.nblkN) < (1L << 32), "conv4: too many tiles for the 32-bit magic divisions");
   KDIP_REQUIRE(p.Cin <= c4_max_cin(tf), "conv4: too many input channels (%d) for the staging-transform table", p.Cin);
   int rc;
 #define C4_GO(T, S, R) rc = launch4<T, S, R>(p, st)

@@ -6,12 +6,12 @@ python build.py >/dev/null
 while [ $# -gt 1 ]; do
   tag=$1; flags=$2; shift 2
   (
-    mkdir -p build_$tag
+    mkdir -p build_c4$tag
     for f in conv4; do
-      /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $flags -x hip -c csrc/$f.hip -o build_$tag/$f.o
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $flags -x hip -c csrc/$f.hip -o build_c4$tag/$f.o
     done
     objs=""
-    for o in build/*.o; do b=$(basename $o); if [ -f build_$tag/$b ]; then objs="$objs build_$tag/$b"; else objs="$objs $o"; fi; done
+    for o in build/*.o; do b=$(basename $o); if [ -f build_c4$tag/$b ]; then objs="$objs build_c4$tag/$b"; else objs="$objs $o"; fi; done
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libkdip_hip_$tag.so $objs
     echo built $tag
   ) &
