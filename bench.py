@@ -310,9 +310,12 @@ def main():
             el = timed_run(parts, idx, full_run, 0)
             rep = sum(pt["den"].replays for pt in parts)
             eag = sum(pt["den"].eager_calls for pt in parts)
+            unconv = sum(pt["den"].cg_unconverged() for pt in parts)     # fixed-trip CG replays whose last residual check still found an active sample
             out["hipgraph_replay"] = {"ms_per_step": round(el / args.steps * 1e3, 3), "value": round(env.world_size * B / (el / args.steps * 100), 5), "unit": "images/s",
-                                      "graphs": sum(len(pt["den"]._graphs) for pt in parts), "replayed_calls_incl_capture_pass": rep, "eager_calls_cg_branch": eag,
-                                      "note": "same steps and protocol as `value`; closed-form guided calls replayed from hipGraphs (captured in an untimed pass), CG-branch calls eager"}
+                                      "graphs": sum(len(pt["den"]._graphs) for pt in parts), "replayed_calls_incl_capture_pass": rep, "eager_calls": eag,
+                                      "cg_fixed_trip_graphs": sum(len(pt["den"].cg_trips) for pt in parts), "cg_unconverged_replays": unconv,
+                                      "note": "same steps and protocol as `value`; every guided call replayed from a hipGraph captured in an untimed pass -- "
+                                              "closed-form calls as they are, CG-branch calls as fixed-trip solves (1.5 x the warm-up call's iterations + 4, no host read)"}
             for pt in parts:
                 pt["den"] = pt["eager_den"]
         except Exception as e:

@@ -95,6 +95,15 @@ int kdip_op_apply(kdip_op* op, void* stream, const float* x_dev, int B, int adjo
  * (may be NULL) receive per-sample iteration counts and scipy-style info (0 = converged). */
 int kdip_op_solve(kdip_op* op, void* stream, const float* y_dev, const float* x0_dev, float var_scalar,
                   const float* var_tensor_dev, int B, float* mat_dev, int* cg_iters_host, int* cg_info_host);
+/* CG trip control of kdip_op_solve's tensor-variance branch.  trips = 0 (default): adaptive -- the per-sample convergence flags are
+ * read back every second iteration (a host synchronisation; cg_iters / cg_info are filled).  trips > 0: exactly `trips` iterations,
+ * no host read at all (capture-safe: samples freeze themselves on the device when they converge, surplus iterations change
+ * nothing); cg_iters / cg_info come back as -1 and kdip_op_cg_unconverged tells afterwards whether `trips` was enough. */
+int kdip_op_set_cg_fixed_trips(kdip_op* op, int trips);
+/* *count_host = number of fixed-trip CG solves on this operator, since the last query, that stopped with an unconverged sample
+ * (sticky device counter, read + cleared here; synchronises the stream).  Callers that replay captured guided calls check it once
+ * per sampler run instead of reading flags every second CG iteration. */
+int kdip_op_cg_unconverged(kdip_op* op, void* stream, int* count_host);
 /* OrthoTransform.__call__ / .inv on [B,3,S,S] (condition/utils.py:59-67,88-139). */
 int kdip_op_ortho(kdip_op* op, void* stream, const float* x_dev, int B, int inverse, float* out_dev);
 
@@ -179,6 +188,18 @@ int kdip_conv_apply(kdip_conv* c, void* stream, const float* x_nchw_dev, int B, 
 int kdip_relu_maxpool(void* stream, const float* x_dev, long planes, int H, int W, int pool, float* y_dev);
 int kdip_lpips_layer(void* stream, const float* f0_dev, const float* f1_dev, const float* lin_w_dev, int B, int C, long HW,
                      float* out_accum_dev /*[B], += */);
+
+/* ------------------------------------------------------------- one guided call (kdip_guided_step)
+ * ConditionOpenAIDenoiser._type_I_guidance_impl (condition/condition.py:167-174) with uncond_pred (:231-274) in ONE entry point:
+ * UNet forward -> p_mean_variance epilogue -> mat-solver (closed form, or CG when tensor_var != 0) -> cotangent -> UNet VJP ->
+ * hat = clamp(x0_mean + sigma^2 * c_in * (a_t * g_raw + unet_vjp), -1, 1).  x_dev [B,3,S,S], t_dev [B] (floored timestep),
+ * y_dev = the measurement in the solver's layout, tables7_host as kdip_x0_epilogue_v1, var_scalar = the scalar x0 variance
+ * (ignored when tensor_var: the learned per-pixel variance is used), ws_dev = kdip_guided_ws_floats(B, S) floats, hat_dev [B,3,S,S].
+ * Capture-safe when the operator is in fixed-trip CG mode (or tensor_var == 0).  Leaves the UNet stash valid for kdip_unet_vjp. */
+long kdip_guided_ws_floats(int B, int S);
+int kdip_guided_call_v1(kdip_unet* u, kdip_op* op, void* stream, const float* x_dev, const float* t_dev, const float* y_dev, int B,
+                        const float* tables7_host, float sigma, float var_scalar, int tensor_var, float* ws_dev, float* hat_dev,
+                        int* cg_iters_host, int* cg_info_host);
 
 /* ------------------------------------------------------------------ low-level test hooks
  * (exercised by tests/ to localise kernel bugs; NHWC tensors of the UNet storage dtype) */

@@ -34,6 +34,10 @@ SIGNATURES = {
     "kdip_op_apply": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, VP]),
     "kdip_op_solve": (C.c_int, [VP, VP, VP, VP, C.c_float, VP, C.c_int, VP, VP, VP]),
     "kdip_op_ortho": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, VP]),
+    "kdip_op_set_cg_fixed_trips": (C.c_int, [VP, C.c_int]),
+    "kdip_op_cg_unconverged": (C.c_int, [VP, VP, c_int_p]),
+    "kdip_guided_ws_floats": (C.c_long, [C.c_int, C.c_int]),
+    "kdip_guided_call_v1": (C.c_int, [VP, VP, VP, VP, VP, VP, C.c_int, VP, C.c_float, C.c_float, C.c_int, VP, VP, VP, VP]),
     "kdip_gather": (C.c_int, [VP, VP, VP, C.c_long, C.c_long, C.c_int, VP]),
     "kdip_scatter": (C.c_int, [VP, VP, VP, C.c_long, C.c_long, C.c_int, VP]),
     "kdip_mask_mul": (C.c_int, [VP, VP, VP, C.c_int, C.c_long, VP]),

@@ -272,6 +272,59 @@ class ConditionOpenAIDenoiser(ConditionDenoiser):
             x0_var = self._axpby(self._vjp_x0(ones), float(s.pow(2)), None, 0.0)
         return x0_mean, x0_var, x0_var
 
+    # ---- one C entry point per guided call (kdip_guided_call_v1, SURVEY.md 8b `kdip_guided_step`): the same kernels in the same
+    # order as uncond_pred -> _solve -> _vjp_x0 -> _combine below, without the ~10 Python / ctypes round trips and the torch.empty
+    # temporaries of that path (one cached workspace per batch size).  Taken for every scalar / learned-variance covariance type
+    # in the pixel basis; `tmpd` (an extra VJP for the variance) and subclasses with their own uncond_pred keep the stepwise path.
+    fused_call = True
+
+    def _type_I_guidance_impl(self, x, sigma):
+        ct = self.x0_cov_type
+        if not (self.fused_call and type(self) is ConditionOpenAIDenoiser and self.ortho_tf_type is None and
+                ct in ('convert', 'analytic', 'pgdm', 'dps', 'diffpir') and hasattr(self.operator, "_h")):
+            return super()._type_I_guidance_impl(x, sigma)
+        import ctypes as C
+        D = self.diffusion
+        s = torch.tensor(sigma_host(sigma), dtype=torch.float32)
+        c_in = float(1 / (s ** 2 + 1) ** 0.5)
+        t = int(self.denoiser.sigma_to_t(sigma).reshape(-1)[0].long())
+        low = float(s) < self.mle_sigma_thres
+        base = float(s.pow(2) / (1 + s.pow(2)))
+        tensor_var = ct == 'convert' and low
+        if ct == 'analytic' and low:
+            assert self.recon_mse is not None
+            v = float(self._mse_list[(self._mse_sigmas - s).abs().argmin()])
+        elif ct == 'dps':
+            v = 0.0
+        elif ct == 'diffpir':
+            assert self.lambda_ is not None
+            v = float(s.pow(2) / self.lambda_)
+        else:
+            v = base
+        B, S = x.shape[0], x.shape[-1]
+        t7 = (C.c_float * 7)(c_in, D.f32('sqrt_recip_alphas_cumprod', t), D.f32('sqrt_recipm1_alphas_cumprod', t), D.f32('log_betas', t),
+                             D.f32('posterior_log_variance_clipped', t), D.f32('posterior_variance', t), D.f32('posterior_mean_coef1', t))
+        key = (B, S, x.device)
+        if getattr(self, "_fused_ws_key", None) != key:
+            self._fused_ws = torch.empty(int(self.lib.kdip_guided_ws_floats(B, S)), device=x.device)
+            self._fused_t = torch.empty(B, device=x.device)
+            self._fused_ws_key = key
+        self._fused_t.fill_(float(t))
+        op = self.operator
+        op._set_ortho(L.OT_NONE)
+        y = op._check(self.y)
+        hat = torch.empty_like(x)
+        iters, info = (C.c_int * B)(), (C.c_int * B)()
+        L.check(self.lib.kdip_guided_call_v1(self.inner_model._h, op._h, L.stream(), L.ptr(x), L.ptr(self._fused_t), L.ptr(y), B, t7,
+                                             float(s), v, int(tensor_var), L.ptr(self._fused_ws), L.ptr(hat), iters, info))
+        op.cg_iters, op.cg_info = list(iters), list(info)
+        if any(i > 0 for i in op.cg_info):
+            warn('CG not converge.')
+        # same stash as uncond_pred leaves behind (x0_raw lives in the call's workspace: valid until the next fused call)
+        n3 = 3 * B * S * S
+        self._stash = (self._fused_ws[3 * n3:4 * n3].view(B, 3, S, S), c_in, t7[1], t7[2], B, S * S)
+        return hat
+
     def _vjp_x0(self, ghat):
         x0_raw, c_in, a_t, b_t, B, HW = self._stash
         ghat = ghat.contiguous()
@@ -340,7 +393,7 @@ def register_mat_solver(name):
 
 def _device_solve(operator, y, x0_mean, theta0_var, ortho_tf):
     mat = operator.solve(y, x0_mean, theta0_var, ortho_tf.code)
-    if any(operator.cg_info):
+    if any(i > 0 for i in operator.cg_info):          # (-1: fixed-trip mode, checked through operator.cg_unconverged())
         warn('CG not converge.')
     return mat
 

@@ -139,6 +139,53 @@ int kdip_op_solve(kdip_op* op, void* stream, const float* y_dev, const float* x0
   KDIP_HIP_CHECK(hipSetDevice(op->c.device));
   return op->c.solve(ST(stream), y_dev, x0_dev, var_scalar, var_tensor_dev, B, mat_dev, cg_iters_host, cg_info_host);
 }
+int kdip_op_set_cg_fixed_trips(kdip_op* op, int trips) {
+  KDIP_REQUIRE(op && trips >= 0 && trips <= 1000, "cg fixed trips must be in [0, 1000]");
+  op->c.cg_fixed_trips = trips;
+  return KDIP_OK;
+}
+int kdip_op_cg_unconverged(kdip_op* op, void* stream, int* count_host) {
+  KDIP_REQUIRE(op && count_host, "null argument");
+  *count_host = 0;
+  if (!op->c.cg.unconverged) return KDIP_OK;            // no CG workspace yet: nothing ran
+  KDIP_HIP_CHECK(hipSetDevice(op->c.device));
+  KDIP_HIP_CHECK(hipMemcpyAsync(count_host, op->c.cg.unconverged, sizeof(int), hipMemcpyDeviceToHost, ST(stream)));
+  KDIP_HIP_CHECK(hipMemsetAsync(op->c.cg.unconverged, 0, sizeof(int), ST(stream)));
+  KDIP_HIP_CHECK(hipStreamSynchronize(ST(stream)));
+  return KDIP_OK;
+}
+
+// One Type-I guided denoiser call in one entry point (the ~10 C calls of kdip_amd.condition._type_I_guidance_impl, same kernels in
+// the same order): UNet forward, p_mean_variance epilogue, mat-solver, cotangent, UNet VJP, likelihood-score assembly, combine.
+long kdip_guided_ws_floats(int B, int S) { return 33L * B * S * S; }
+int kdip_guided_call_v1(kdip_unet* u, kdip_op* op, void* stream, const float* x_dev, const float* t_dev, const float* y_dev, int B,
+                        const float* t7, float sigma, float var_scalar, int tensor_var, float* ws, float* hat_dev,
+                        int* cg_iters_host, int* cg_info_host) {
+  KDIP_REQUIRE(u && op && x_dev && t_dev && y_dev && t7 && ws && hat_dev, "null argument");
+  KDIP_REQUIRE(u->u.cfg.out_channels == 6 && u->u.cfg.in_channels == 3, "guided_call_v1: the V1 path needs a learn-sigma UNet (3 -> 6 channels)");
+  KDIP_REQUIRE(op->c.N == u->u.cfg.image_size, "guided_call_v1: operator size %d != UNet image size %d", op->c.N, u->u.cfg.image_size);
+  hipStream_t st = ST(stream);
+  const int S = u->u.cfg.image_size;
+  const long HW = (long)S * S, n3 = 3L * B * HW;
+  float* out6 = ws;                 // [B,6,S,S]
+  float* x0_mean = out6 + 2 * n3;   // [B,3,S,S] each
+  float* x0_raw = x0_mean + n3;
+  float* var = x0_raw + n3;
+  float* mat = var + n3;
+  float* cot = mat + n3;            // [B,6,S,S]
+  float* g_raw = cot + 2 * n3;
+  float* ug = g_raw + n3;
+  float* score = ug + n3;
+  KDIP_HIP_CHECK(hipSetDevice(u->u.device));
+  API_CK(u->u.run(st, x_dev, t_dev, B, t7[0], out6, nullptr, nullptr, 1));
+  API_CK(kdip_x0_epilogue_v1(stream, out6, x_dev, B, HW, t7, x0_mean, x0_raw, tensor_var ? var : nullptr));
+  API_CK(op->c.solve(st, y_dev, x0_mean, var_scalar, tensor_var ? var : nullptr, B, mat, cg_iters_host, cg_info_host));
+  API_CK(vjp_cotangent_v1(st, mat, x0_raw, B, HW, t7[2], cot, g_raw));
+  API_CK(u->u.vjp(st, cot, ug));
+  API_CK(axpby(st, g_raw, t7[0] * t7[1], ug, t7[0], n3, score));                     // c_in * (a_t * g_raw + unet_vjp)
+  return guidance_combine(st, x0_mean, score, 1.f, nullptr, 0.f, sigma * sigma, n3, hat_dev);
+}
+
 int kdip_op_ortho(kdip_op* op, void* stream, const float* x_dev, int B, int inverse, float* out_dev) {
   KDIP_REQUIRE(op && x_dev && out_dev, "null argument");
   KDIP_HIP_CHECK(hipSetDevice(op->c.device));

@@ -59,6 +59,9 @@ constexpr int C3_LDS_TOTAL = C3_LDS + 64 + 512;           // + dummy staging slo
 #ifndef C3_STAGGER
 #define C3_STAGGER 0            // experiment: start delay of block j = (j / 8 % 16) * C3_STAGGER * 64 cycles (de-synchronises the chip-wide epilogue bursts)
 #endif
+#ifndef C3_ANTIPHASE
+#define C3_ANTIPHASE 0          // experiment: the second-resident block of a CU (LDS base != 0) starts C3_ANTIPHASE x 8128 cycles late, so that
+#endif                          // one block's epilogue (VALU / memory) runs beside the other block's K loop (MFMA)
 #ifndef C3_BLOCKS_PER_CU
 #define C3_BLOCKS_PER_CU 2
 #endif
@@ -152,6 +155,9 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
   const int nper = gridDim.x >> 3;                       // blocks per XCD share
   int cur = xstart + (blockIdx.x >> 3);
   if (cur >= xend) return;
+  if (C3_ANTIPHASE) {
+    if (__builtin_amdgcn_s_getreg(0x3806) != 0) { for (int i = 0; i < C3_ANTIPHASE; ++i) __builtin_amdgcn_s_sleep(127); }      // HW_REG_LDS_ALLOC.LDS_BASE
+  }
   if (C3_STAGGER) { for (int i = (int)((blockIdx.x >> 3) & 15); i > 0; --i) __builtin_amdgcn_s_sleep(C3_STAGGER); }
   C3_STAMP(0);
 #if C3_TIMING

@@ -69,10 +69,11 @@ struct CgState {      // device arrays of length B
   double *rr, *pq, *rho_prev, *atol2;
   float *alpha, *beta;
   int *active, *iters, *any_active;
+  int* unconverged;      // sticky: number of fixed-trip solves that stopped with an active sample (kdip_op_cg_unconverged reads + clears it)
 };
 int cg_dot(hipStream_t st, const float* a, const float* b, int B, long per, double* out);
 int cg_init(hipStream_t st, CgState s, int B, float tol);                     // uses rr = b.b
-int cg_step_a(hipStream_t st, CgState s, int B, int it);                      // active/beta from rr
+int cg_step_a(hipStream_t st, CgState s, int B, int it, int count_unconverged = 0);   // active/beta from rr; count_unconverged: unconverged += any_active
 int cg_update_p(hipStream_t st, CgState s, const float* r, float* p, int B, long per);
 int cg_step_b(hipStream_t st, CgState s, int B);                              // alpha from rho/pq
 int cg_update_xr(hipStream_t st, CgState s, float* x, float* r, const float* p, const float* q, int B, long per);

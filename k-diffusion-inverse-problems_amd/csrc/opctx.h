@@ -28,6 +28,7 @@ struct OpCtx {
   CgState cg{};
   double* dtmp = nullptr;
   int* h_any = nullptr;            // pinned host flag
+  int cg_fixed_trips = 0;          // > 0: every CG solve runs exactly this many iterations with no host read (hipGraph capture); converged samples stay frozen
   std::vector<void*> allocs;
 
   ~OpCtx();

@@ -553,7 +553,7 @@ int cg_init(hipStream_t st, CgState s, int B, float tol) {
   hipLaunchKernelGGL(cg_init_kernel, dim3(1), dim3(1024), 0, st, s, B, tol);
   KDIP_LAUNCH_CHECK(); return KDIP_OK;
 }
-__global__ void cg_step_a_kernel(CgState s, int B, int it) {
+__global__ void cg_step_a_kernel(CgState s, int B, int it, int count_unconverged) {
   __shared__ int any;
   int b = threadIdx.x;
   if (b == 0) any = 0;
@@ -566,10 +566,10 @@ __global__ void cg_step_a_kernel(CgState s, int B, int it) {
     if (act) { s.iters[b] += 1; atomicOr(&any, 1); }
   }
   __syncthreads();
-  if (b == 0) *s.any_active = any;
+  if (b == 0) { *s.any_active = any; if (count_unconverged && any) *s.unconverged += 1; }
 }
-int cg_step_a(hipStream_t st, CgState s, int B, int it) {
-  hipLaunchKernelGGL(cg_step_a_kernel, dim3(1), dim3(1024), 0, st, s, B, it);
+int cg_step_a(hipStream_t st, CgState s, int B, int it, int count_unconverged) {
+  hipLaunchKernelGGL(cg_step_a_kernel, dim3(1), dim3(1024), 0, st, s, B, it, count_unconverged);
   KDIP_LAUNCH_CHECK(); return KDIP_OK;
 }
 __global__ void cg_update_p_kernel(CgState s, const float* r, float* p, long per, long n) {

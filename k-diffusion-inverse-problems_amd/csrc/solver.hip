@@ -51,6 +51,8 @@ int OpCtx::ensure_ws(int B) {
   CK(dmalloc(this, (void**)&cg.active, sizeof(int) * B));
   CK(dmalloc(this, (void**)&cg.iters, sizeof(int) * B));
   CK(dmalloc(this, (void**)&cg.any_active, sizeof(int)));
+  CK(dmalloc(this, (void**)&cg.unconverged, sizeof(int)));
+  KDIP_HIP_CHECK(hipMemset(cg.unconverged, 0, sizeof(int)));
   CK(dmalloc(this, (void**)&dtmp, sizeof(double) * B));
   wsB = B;
   return KDIP_OK;
@@ -195,10 +197,15 @@ static int cg_solve(OpCtx* c, hipStream_t st, const std::function<int(const floa
   CK(cg_dot(st, b, b, B, per, c->cg.rr));
   CK(cg_init(st, c->cg, B, 1e-4f));
   int it = 0;
-  for (; it < maxiter; ++it) {
+  // fixed-trip mode (capture-safe, kdip_op_set_cg_fixed_trips): no convergence flag is read back; every sample freezes itself on
+  // the device when it converges (cg_step_a), so surplus iterations change nothing.  One more residual check after the last
+  // update leaves `any_active` = "some sample would have needed more iterations" for kdip_op_cg_unconverged.
+  const int fixed = c->cg_fixed_trips;
+  for (; it < (fixed > 0 ? fixed + 1 : maxiter); ++it) {
     CK(cg_dot(st, r, r, B, per, c->cg.rr));
-    CK(cg_step_a(st, c->cg, B, it));
-    if (it >= 2 && (it % 2) == 0) {
+    CK(cg_step_a(st, c->cg, B, it, fixed > 0 && it == fixed));
+    if (fixed > 0) { if (it == fixed) break; }
+    else if (it >= 2 && (it % 2) == 0) {
       KDIP_HIP_CHECK(hipMemcpyAsync(c->h_any, c->cg.any_active, sizeof(int), hipMemcpyDeviceToHost, st));
       KDIP_HIP_CHECK(hipStreamSynchronize(st));
       if (!c->h_any[0]) break;
@@ -208,6 +215,10 @@ static int cg_solve(OpCtx* c, hipStream_t st, const std::function<int(const floa
     CK(cg_dot(st, p, q, B, per, c->cg.pq));
     CK(cg_step_b(st, c->cg, B));
     CK(cg_update_xr(st, c->cg, x, r, p, q, B, per));
+  }
+  if (fixed > 0) {           // no host round trip: the counts are not known here
+    for (int i = 0; i < B; ++i) { if (iters_host) iters_host[i] = -1; if (info_host) info_host[i] = -1; }
+    return KDIP_OK;
   }
   if (iters_host || info_host) {
     std::vector<int> hi(B), ha(B);

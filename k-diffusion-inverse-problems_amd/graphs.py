@@ -9,7 +9,11 @@ What is capture-safe and what is not:
   * every libkdip_hip entry point on the closed-form path is (no allocation after the first call at a batch size -- workspaces are
     planned per batch on the host --, no host synchronisation, hipMemsetAsync only);
   * the CG branch (tensor-valued covariance below `mle_sigma_thres`: 42 of the 199 calls of BASELINE configs[1]) reads its
-    per-sample convergence flags back to the host every second iteration, so those calls stay eager.
+    per-sample convergence flags back to the host every second iteration when run eagerly.  For capture the operator is put
+    into FIXED-TRIP mode (kdip_op_set_cg_fixed_trips): the eager warm-up call reports the iterations this sigma needs, the graph
+    runs 1.5 x that + 4 iterations with no host read -- samples freeze themselves on the device when they converge, so surplus
+    iterations change nothing --, and a sticky device counter records replays whose last residual check still found an active
+    sample (`cg_unconverged()`, read once per sampler run).
 
 Captured graphs hold raw pointers into the UNet handle's workspace arenas and to the denoiser's measurement tensors.  The handle
 regrows (frees + re-allocates) its arenas when a call at a new batch shape does not fit, so every graph records the handle's
@@ -23,9 +27,12 @@ from .external import sigma_host
 
 
 class GraphedDenoiser:
-    def __init__(self, den, enabled=True):
+    def __init__(self, den, enabled=True, capture_cg=True, cg_margin=1.5):
         self.den = den
         self.enabled = enabled
+        self.capture_cg = capture_cg   # capture the CG branch too, as fixed-trip solves (trips = margin * iterations of the warm-up + 4)
+        self.cg_margin = cg_margin
+        self.cg_trips = {}
         self._graphs = {}          # (sigma, shape) -> (graph, static_x, static_out)
         self.replays = 0
         self.eager_calls = 0
@@ -55,17 +62,27 @@ class GraphedDenoiser:
             self._graphs.clear()
             self._bound = b
 
+    def _is_cg_branch(self, sigma_value):
+        den = self.den
+        tensor_cov = getattr(den, "x0_cov_type", None) in ("convert", "tmpd") or not hasattr(den, "x0_cov_type")   # V2: learned variances
+        uses_solver = den.guidance in ("I", "II", "autoI", "dps+mle", "pgdm+mle")
+        return uses_solver and tensor_cov and sigma_value < den.mle_sigma_thres
+
     def capturable(self, sigma_value):
         den = self.den
         if den.guidance in ("stsl", "stsl+mle"):                 # draws Hutchinson probes with the device generator per call
             return False
-        tensor_cov = getattr(den, "x0_cov_type", None) in ("convert", "tmpd") or not hasattr(den, "x0_cov_type")   # V2: learned variances
-        uses_solver = den.guidance in ("I", "II", "autoI", "dps+mle", "pgdm+mle")
-        if uses_solver and tensor_cov and sigma_value < den.mle_sigma_thres:
-            return False                                          # CG branch: host reads the convergence flags
         if getattr(den, "x0_cov_type", None) == "tmpd":
             return False
+        if self._is_cg_branch(sigma_value):                       # CG branch: capturable in fixed-trip mode only
+            return self.capture_cg and hasattr(den.operator, "set_cg_fixed_trips")
         return True
+
+    def cg_unconverged(self):
+        """Number of replayed / captured fixed-trip CG solves, since the last query, that stopped with an unconverged sample: check
+        once per sampler run (one stream synchronisation) -- 0 means every replay was as converged as the adaptive solver."""
+        op = getattr(self.den, "operator", None)
+        return op.cg_unconverged() if hasattr(op, "cg_unconverged") else 0
 
     def __call__(self, x, sigma):
         s = sigma_host(sigma)
@@ -81,12 +98,25 @@ class GraphedDenoiser:
             ssig._kdip_host_value = float(s)
             self.den(sx, ssig)                                    # eager warm-up: sizes workspaces, sets kernel attributes
             torch.cuda.current_stream().synchronize()
+            cg = self._is_cg_branch(s)
+            if cg:      # the adaptive warm-up call told how many CG iterations this sigma needs: capture that many + a margin
+                op = self.den.operator
+                need = max([i for i in getattr(op, "cg_iters", [0]) if i >= 0] or [0])
+                trips = int(need * self.cg_margin) + 4
+                op.set_cg_fixed_trips(trips)
+                self.cg_trips[key] = trips
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):     # (capture runs on torch's capture stream = current stream)
-                so = self.den(sx, ssig)
+            try:
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):     # (capture runs on torch's capture stream = current stream)
+                    so = self.den(sx, ssig)
+            finally:
+                if cg:
+                    self.den.operator.set_cg_fixed_trips(0)       # eager calls keep the adaptive solver
             ent = (g, sx, so)
             if self._bindings() != self._bound:                   # the warm-up call itself regrew the arenas: older graphs are stale,
-                self._graphs.clear()                              # this one was captured against the new arenas
+                if self._graphs:                                  # this one was captured against the new arenas
+                    self.invalidations += 1
+                self._graphs.clear()
                 self._bound = self._bindings()
             self._graphs[key] = ent
         g, sx, so = ent

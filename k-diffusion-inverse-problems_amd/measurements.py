@@ -126,6 +126,19 @@ class LinearOperator(ABC):
         self.cg_iters, self.cg_info = list(iters), list(info)
         return mat
 
+    def set_cg_fixed_trips(self, trips):
+        """trips > 0: every later tensor-variance solve runs exactly `trips` CG iterations with no host read (capture-safe: samples
+        freeze themselves on the device when they converge); 0: adaptive (flags read back every second iteration)."""
+        L.check(self.lib.kdip_op_set_cg_fixed_trips(self._h, int(trips)))
+        self._cg_fixed_trips = int(trips)
+
+    def cg_unconverged(self):
+        """Number of fixed-trip CG solves since the last query that stopped with an unconverged sample (sticky device counter, read
+        and cleared; synchronises the stream)."""
+        n = C.c_int(0)
+        L.check(self.lib.kdip_op_cg_unconverged(self._h, L.stream(), C.byref(n)))
+        return int(n.value)
+
     def forward_adjoint(self, r):
         """True adjoint of the noiseless `forward` (what autograd applies in DPS, condition.py:143-146)."""
         return self.transpose(r)

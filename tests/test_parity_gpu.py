@@ -537,15 +537,15 @@ def test_eps_mse_loss_value(tiny):
 
 def test_hipgraph_capture_replay(gold, tiny):
     """Capture / replay of guided calls (kdip_amd.graphs.GraphedDenoiser): the closed-form branch is captured once per sigma into a
-    hipGraph and replayed for new inputs with results equal to the eager call (fp64-atomic order noise only); the CG branch stays
-    eager (it reads convergence flags back to the host)."""
+    hipGraph and replayed for new inputs with results equal to the eager call (fp64-atomic order noise only); with capture_cg=False
+    the CG branch stays eager (it reads convergence flags back to the host; test_hipgraph_cg_branch_fixed_trips covers its capture)."""
     import kdip_amd.condition as kc
     from kdip_amd.graphs import GraphedDenoiser
     models, D, sd, cfg = tiny
     hop, oop, (y, yf), x0 = make_ops("gaussian_blur", gold)
     den = kc.ConditionOpenAIDenoiser(inner_model=models["f32"], diffusion=D, x0_cov_type="convert", recon_mse=None, operator=hop,
                                      measurement=(y.cuda(), yf.cuda()), guidance="I", device="cuda")     # (f32 mode: run-to-run noise is ~1e-6;
-    gd = GraphedDenoiser(den)                                                                            #  bf16 re-rounds the atomics-order noise to ~1e-3)
+    gd = GraphedDenoiser(den, capture_cg=False)                                                          #  bf16 re-rounds the atomics-order noise to ~1e-3)
     g = torch.Generator().manual_seed(21)
     xs = [(x0 + 1.5 * torch.randn(1, 3, 64, 64, generator=g)).cuda() for _ in range(3)]
     sig = torch.tensor([1.5], device="cuda")
@@ -590,3 +590,54 @@ def test_hipgraph_invalidated_by_workspace_regrowth(gold):
     assert float((o1b - o1).abs().max()) < 1e-4
     assert float((o4 - den(x4, s4)).abs().max()) < 1e-4
     assert float((gd(x1, s1) - den(x1, s1)).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("sigma_v", [1.5, 0.12])
+def test_fused_guided_call_equals_stepwise(gold, tiny, sigma_v):
+    """kdip_guided_call_v1 (one C entry point per Type-I guided call) = the stepwise path (uncond_pred -> solver -> cotangent -> VJP ->
+    combine through ~10 C calls): same kernels, same order; closed-form branch and CG branch (adaptive and fixed-trip)."""
+    import kdip_amd.condition as kc
+    models, D, sd, cfg = tiny
+    hop, oop, (y, yf), x0 = make_ops("gaussian_blur", gold)
+    g = torch.Generator().manual_seed(31)
+    x = (x0 + sigma_v * torch.randn(2, 3, 64, 64, generator=g)).cuda()
+    sig = torch.full((2,), sigma_v, device="cuda")
+    outs = {}
+    for fused in (False, True):
+        den = kc.ConditionOpenAIDenoiser(inner_model=models["f32"], diffusion=D, x0_cov_type="convert", recon_mse=None, operator=hop,
+                                         measurement=(y.cuda(), yf.cuda()), guidance="I", device="cuda")
+        den.fused_call = fused
+        outs[fused] = den(x, sig)
+        iters = list(hop.cg_iters)
+    assert float((outs[True] - outs[False]).abs().max()) < 2e-5          # fp64-atomic order noise of two runs of the same kernels
+    if sigma_v < 0.2:
+        assert max(iters) > 0
+        hop.set_cg_fixed_trips(int(1.5 * max(iters)) + 4)                 # capture-safe mode: no host read, surplus iterations are no-ops
+        try:
+            fixed = den(x, sig)
+            assert hop.cg_iters == [-1, -1] and hop.cg_unconverged() == 0
+            assert float((fixed - outs[True]).abs().max()) < 2e-5
+            hop.set_cg_fixed_trips(1)                                     # too few trips: flagged by the sticky counter
+            den(x, sig)
+            assert hop.cg_unconverged() == 1 and hop.cg_unconverged() == 0
+        finally:
+            hop.set_cg_fixed_trips(0)
+
+
+def test_hipgraph_cg_branch_fixed_trips(gold, tiny):
+    """The CG branch captured as a fixed-trip solve: replay = eager adaptive call, no unconverged replay."""
+    import kdip_amd.condition as kc
+    from kdip_amd.graphs import GraphedDenoiser
+    models, D, sd, cfg = tiny
+    hop, oop, (y, yf), x0 = make_ops("gaussian_blur", gold)
+    den = kc.ConditionOpenAIDenoiser(inner_model=models["f32"], diffusion=D, x0_cov_type="convert", recon_mse=None, operator=hop,
+                                     measurement=(y.cuda(), yf.cuda()), guidance="I", device="cuda")
+    gd = GraphedDenoiser(den)
+    g = torch.Generator().manual_seed(23)
+    xs = [(x0 + 0.12 * torch.randn(1, 3, 64, 64, generator=g)).cuda() for _ in range(3)]
+    lo = torch.tensor([0.12], device="cuda")
+    outs = [gd(x, lo) for x in xs]
+    assert gd.replays == 3 and gd.eager_calls == 0 and len(gd.cg_trips) == 1
+    assert gd.cg_unconverged() == 0
+    for x, o in zip(xs, outs):
+        assert float((o - den(x, lo)).abs().max()) < 1e-4

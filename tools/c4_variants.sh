@@ -7,7 +7,7 @@ while [ $# -gt 1 ]; do
   tag=$1; flags=$2; shift 2
   (
     mkdir -p build_c4$tag
-    for f in conv4; do
+    for f in ${C4V_FILES:-conv4}; do
       /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $flags -x hip -c csrc/$f.hip -o build_c4$tag/$f.o
     done
     objs=""
