@@ -415,8 +415,15 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
           vec_store(nbuf, i, transform(cn, i, o, o2));
         }
         if (!C3_ABL_NOSTG && tap < C3_MAXV) vec_load_asm(cn * 64, tap);
-        if (AUXPF && tap == 6) asm volatile("global_load_dword %0, %1, %2" : "=v"(pf0) : "v"(aux_off), "s"(aux_img) : "memory");
-        if (AUXPF && tap == 7) asm volatile("global_load_dword %0, %1, %2 offset:128" : "=v"(pf1) : "v"(aux_off), "s"(aux_img) : "memory");
+        if (AUXPF && (tap == 6 || tap == 7)) {
+          // mode 2: only the tile's LAST chunk touches the real lines (a few us ahead of the epilogue: still in L2 when it reads
+          // them); the other chunks issue the same instruction on an L2-hot dummy line so that the counted waits stay uniform
+          const bool real = C3_AUX_PREFETCH != 2 || last;
+          const bf16_t* ab_ = real ? aux_img : (const bf16_t*)p.wp;
+          const unsigned ao_ = real ? aux_off : 0u;
+          if (tap == 6) asm volatile("global_load_dword %0, %1, %2" : "=v"(pf0) : "v"(ao_), "s"(ab_) : "memory");
+          else asm volatile("global_load_dword %0, %1, %2 offset:128" : "=v"(pf1) : "v"(ao_), "s"(ab_) : "memory");
+        }
         // explicit software pipeline of the fragment reads: the k-step-0 patch fragments of stage s+1 are requested under the
         // k-step-1 MFMAs of stage s (same chunk: the patch buffer is stable) and carried across the barrier in pa[]; only the
         // weight fragments wait for the barrier (their DMA is published by it)

@@ -758,13 +758,15 @@ int conv4_debug_timing(void* buf) {
 }
 int conv4_tf_max_cin(int tf) { return c4_max_cin(tf); }
 
-// tf / stm / res: fusion mode of the launch.  Automatic choice (measured against conv3, tools/conv4_micro.py, 8 and 16 images of
-// 128 -> 128 and 256 -> 128 @ 256^2): the ping-pong K loop wins where the epilogue is light -- plain / forward-statistics
-// epilogues without a residual (-3 ... -6 %) --; with a residual or the GroupNorm-backward epilogue / staging the block-wide
-// epilogue (nothing overlaps it: both wave groups reach it together) gives the gain back (+0 ... +5 %), those stay on conv3.
+// tf / stm / res: fusion mode of the launch.  Generation 0 (automatic) keeps every launch on conv3: measured in the network
+// (bench.py roofline leg, 8 images per launch) the third-generation kernel is level with conv3 at 256 -> 128 @ 256^2 (297 vs 293 us)
+// and slower at 128 -> 128 with the GroupNorm staging (186 vs 161 us), and the whole step is unchanged (40.7 ms both ways);
+// in the back-to-back micro-benchmark it wins 3 - 6 % on light epilogues and loses 0 - 5 % on the residual / GroupNorm-backward
+// ones.  KDIP_CONV_GEN=4 / kdip_debug_conv_generation(4) selects it wherever the shape allows.
 bool conv4_shape_ok(const Conv3Params& p, int tf, int stm, bool res) {
   if (g_conv_gen.load() == 3) return false;
-  if (g_conv_gen.load() == 0 && (res || stm == 2 || tf == 2)) return false;
+  if (g_conv_gen.load() != 4) return false;
+  (void)tf; (void)stm; (void)res;
   if (p.H % C4_TH != 0 || p.W % C4_TW != 0 || p.Cout % C4_BN != 0 || p.Cin % 32 != 0 || p.Cout > C4_MAXCOUT) return false;
   const long tiles = (long)p.B * (p.H / C4_TH) * (p.W / C4_TW) * (p.Cout / C4_BN);
   return g_conv_gen.load() == 4 || tiles >= C4_MIN_TILES;
