@@ -121,6 +121,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="images per GPU (BASELINE configs[1]: 16)")
     ap.add_argument("--no-large-batch", action="store_true", help="skip the extra throughput leg at batch 128 (N = 1 only)")
     ap.add_argument("--streams", type=int, default=2, help="part-batches per GPU, each on its own HIP stream + host thread")
+    ap.add_argument("--cu-split", action="store_true", help="give each part-batch stream its own share of the compute units (CU-masked HIP streams)")
     ap.add_argument("--dtype", choices=("bf16", "f32"), default="bf16", help="UNet storage / MFMA type (f32 = the exact-f32 parity mode)")
     ap.add_argument("--no-graph-leg", action="store_true", help="skip the extra leg that replays the guided calls from hipGraphs (N = 1 only)")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the extra leg that times the same workload in the f32 parity mode (N = 1 only)")
@@ -165,7 +166,16 @@ def main():
             den = kc.ConditionOpenAIDenoiser(inner_model=model, diffusion=D, x0_cov_type="convert", recon_mse=None, operator=op,
                                              measurement=meas, guidance="I", mle_sigma_thres=0.2, device=dev).eval()
             noise = torch.randn(Bk, 3, S, S, device=dev, generator=torch.Generator(device=dev).manual_seed(3 + 1000 * rank + 100 * k))
-            parts.append(dict(den=den, x0=x0, noise=noise, stream=torch.cuda.Stream(device=dev) if nstreams > 1 else torch.cuda.current_stream(), B=Bk))
+            if nstreams > 1 and args.cu_split:      # stream k owns CU indices [32 k / n, 32 (k + 1) / n) of every XCD (8 mask bits per CU index)
+                lo, hi = 32 * k // nstreams, 32 * (k + 1) // nstreams
+                bits = sum(0xff << (8 * j) for j in range(lo, hi))
+                words = (C.c_uint * 8)(*[(bits >> (32 * w)) & 0xffffffff for w in range(8)])
+                hs = C.c_void_p()
+                L.check(lib.kdip_stream_create_cu_mask(dev.index if hasattr(dev, "index") and dev.index is not None else torch.cuda.current_device(), words, 8, C.byref(hs)))
+                stream = torch.cuda.ExternalStream(hs.value, device=dev)
+            else:
+                stream = torch.cuda.Stream(device=dev) if nstreams > 1 else torch.cuda.current_stream()
+            parts.append(dict(den=den, x0=x0, noise=noise, stream=stream, B=Bk))
         torch.cuda.synchronize()
         return parts
 

@@ -189,6 +189,15 @@ int kdip_relu_maxpool(void* stream, const float* x_dev, long planes, int H, int 
 int kdip_lpips_layer(void* stream, const float* f0_dev, const float* f1_dev, const float* lin_w_dev, int B, int C, long HW,
                      float* out_accum_dev /*[B], += */);
 
+/* ------------------------------------------------------------- CU-masked streams
+ * A HIP stream restricted to the compute units whose bits are set in mask_words (hipExtStreamCreateWithCUMask).  Two part-batches
+ * of a GPU's batch on two such streams with disjoint masks share the chip by SPACE: one stream's persistent conv launches (every
+ * CU's LDS full) no longer lock the other stream's small-map kernels out.  kdip_debug_cu_census reports where blocks of a stream
+ * run (out_host[2b] = HW_ID, out_host[2b+1] = XCC_ID of block b). */
+int kdip_stream_create_cu_mask(int device, const unsigned* mask_words, int nwords, void** stream_out);
+int kdip_stream_destroy(void* stream);
+int kdip_debug_cu_census(void* stream, int blocks, unsigned* out_host);
+
 /* ------------------------------------------------------------- one guided call (kdip_guided_step)
  * ConditionOpenAIDenoiser._type_I_guidance_impl (condition/condition.py:167-174) with uncond_pred (:231-274) in ONE entry point:
  * UNet forward -> p_mean_variance epilogue -> mat-solver (closed form, or CG when tensor_var != 0) -> cotangent -> UNet VJP ->

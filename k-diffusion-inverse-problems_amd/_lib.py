@@ -36,6 +36,9 @@ SIGNATURES = {
     "kdip_op_ortho": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, VP]),
     "kdip_op_set_cg_fixed_trips": (C.c_int, [VP, C.c_int]),
     "kdip_op_cg_unconverged": (C.c_int, [VP, VP, c_int_p]),
+    "kdip_stream_create_cu_mask": (C.c_int, [C.c_int, VP, C.c_int, C.POINTER(VP)]),
+    "kdip_stream_destroy": (C.c_int, [VP]),
+    "kdip_debug_cu_census": (C.c_int, [VP, C.c_int, VP]),
     "kdip_guided_ws_floats": (C.c_long, [C.c_int, C.c_int]),
     "kdip_guided_call_v1": (C.c_int, [VP, VP, VP, VP, VP, VP, C.c_int, VP, C.c_float, C.c_float, C.c_int, VP, VP, VP, VP]),
     "kdip_gather": (C.c_int, [VP, VP, VP, C.c_long, C.c_long, C.c_int, VP]),

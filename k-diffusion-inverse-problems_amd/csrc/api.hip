@@ -96,6 +96,52 @@ long kdip_unet_workspace_bytes(kdip_unet* u, int B) {
   return (long)(u->u.persist.cap + u->u.scratch.cap);
 }
 
+// ------------------------------------------------------------------ CU-masked streams (chip partitioning) ----
+// Two part-batches of a GPU's batch can each be given their own set of compute units: the persistent conv kernels of one stream
+// then never lock the other stream's latency-bound small-map kernels out of the chip (every CU's LDS is full while they run).
+int kdip_stream_create_cu_mask(int device, const unsigned* mask_words, int nwords, void** stream_out) {
+  KDIP_REQUIRE(mask_words && nwords > 0 && stream_out, "null argument");
+  KDIP_HIP_CHECK(hipSetDevice(device));
+  hipStream_t st = nullptr;
+  KDIP_HIP_CHECK(hipExtStreamCreateWithCUMask(&st, (uint32_t)nwords, mask_words));
+  // measured on MI355X (tools/cu_census.py): each group of 8 mask bits addresses ONE CU index in all 8 XCDs (a CU index is
+  // enabled when any of its 8 bits is set), so the stream owns 8 CUs per non-zero byte
+  int ncus = 0;
+  for (int w = 0; w < nwords; ++w)
+    for (int b = 0; b < 4; ++b) ncus += ((mask_words[w] >> (8 * b)) & 0xffu) ? 8 : 0;
+  stream_register_cus(st, ncus);
+  *stream_out = (void*)st;
+  return KDIP_OK;
+}
+int kdip_stream_destroy(void* stream) {
+  stream_register_cus(ST(stream), 0);
+  if (stream) KDIP_HIP_CHECK(hipStreamDestroy(ST(stream)));
+  return KDIP_OK;
+}
+namespace {
+__global__ void cu_census_kernel(unsigned* out, int spin) {
+  // one record per block: HW_ID (wave / simd / cu / sh / se ids) and XCC_ID
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 4);          // HW_REG_HW_ID, all 32 bits
+    out[2 * blockIdx.x + 1] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20);      // HW_REG_XCC_ID, bits 3:0
+  }
+  for (int i = 0; i < spin; ++i) __builtin_amdgcn_s_sleep(64);                     // keep the block resident so that others spread out
+}
+}  // namespace
+// Debug aid: launches `blocks` one-wave blocks that each hold a 64 KB LDS allocation for a moment and records where they ran:
+// out_host[2 b] = HW_ID, out_host[2 b + 1] = XCC_ID of block b.  Used to learn which CU-mask bit addresses which XCD / CU.
+int kdip_debug_cu_census(void* stream, int blocks, unsigned* out_host) {
+  KDIP_REQUIRE(blocks > 0 && blocks <= 4096 && out_host, "bad argument");
+  unsigned* d = nullptr;
+  KDIP_HIP_CHECK(hipMalloc((void**)&d, sizeof(unsigned) * 2 * blocks));
+  hipLaunchKernelGGL(cu_census_kernel, dim3(blocks), dim3(64), 65536, ST(stream), d, 200);
+  hipError_t e = hipMemcpyAsync(out_host, d, sizeof(unsigned) * 2 * blocks, hipMemcpyDeviceToHost, ST(stream));
+  if (e == hipSuccess) e = hipStreamSynchronize(ST(stream));
+  (void)hipFree(d);
+  KDIP_HIP_CHECK(e);
+  return KDIP_OK;
+}
+
 // -------------------------------------------------------------------------- operators ----
 int kdip_op_create(int device, int kind, int image_size, int scale_factor, float sigma_s, kdip_op** out) {
   KDIP_REQUIRE(out, "null output handle");

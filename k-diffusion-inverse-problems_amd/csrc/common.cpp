@@ -14,6 +14,20 @@ int set_error(int code, const char* fmt, ...) {
   return code;
 }
 
+static std::mutex g_cus_mu;
+static std::vector<std::pair<hipStream_t, int>> g_stream_cus;
+void stream_register_cus(hipStream_t st, int ncus) {
+  std::lock_guard<std::mutex> lk(g_cus_mu);
+  for (size_t i = 0; i < g_stream_cus.size(); ++i)
+    if (g_stream_cus[i].first == st) { g_stream_cus.erase(g_stream_cus.begin() + i); break; }
+  if (ncus > 0) g_stream_cus.push_back({st, ncus});
+}
+int stream_cus(hipStream_t st, int device_cus) {
+  std::lock_guard<std::mutex> lk(g_cus_mu);
+  for (auto& e : g_stream_cus) if (e.first == st) return e.second < device_cus ? e.second : device_cus;
+  return device_cus;
+}
+
 bool g_prof_on = false;
 struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; const char* tag; long d[4]; };
 static std::vector<ProfRec> g_recs;            // guarded by g_prof_mu (launches may come from several host threads)

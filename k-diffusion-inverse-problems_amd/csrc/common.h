@@ -127,6 +127,11 @@ __device__ inline float wave_max(float v) {
   return v;
 }
 
+// compute units a stream may use: the device's count, or what kdip_stream_create_cu_mask registered for a CU-masked stream
+// (persistent kernels size their grids by it)
+void stream_register_cus(hipStream_t st, int ncus);      // ncus <= 0: forget
+int stream_cus(hipStream_t st, int device_cus);
+
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- opt-in per-launch profiler (HIP events on the launch stream; used by bench.py's roofline leg) ----

@@ -770,7 +770,7 @@ int launch3(const Conv3Params& p, hipStream_t st) {
     num_cu.store(n > 0 ? n : 256);
   }
   const long ntiles8 = ((long)p.mtiles * p.nblkN + 7) / 8 * 8;
-  long grid = (long)C3_BLOCKS_PER_CU * num_cu.load() / 8 * 8;
+  long grid = (long)C3_BLOCKS_PER_CU * stream_cus(st, num_cu.load()) / 8 * 8;
   if (grid > ntiles8) grid = ntiles8;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), C3_LDS_TOTAL, st, p);
   return KDIP_OK;

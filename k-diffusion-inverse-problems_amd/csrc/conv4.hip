@@ -738,7 +738,7 @@ int launch4(const Conv3Params& p, hipStream_t st) {
     num_cu.store(n > 0 ? n : 256);
   }
   const long ntiles8 = ((long)p.mtiles * p.nblkN + 7) / 8 * 8;
-  long grid = (long)num_cu.load() / 8 * 8;               // persistent launch: one resident block per CU, a multiple of 8 (one share per XCD)
+  long grid = (long)stream_cus(st, num_cu.load()) / 8 * 8;               // persistent launch: one resident block per CU, a multiple of 8 (one share per XCD)
   if (grid > ntiles8) grid = ntiles8;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C4_NTHR), C4_LDS_TOTAL, st, p);
   return KDIP_OK;

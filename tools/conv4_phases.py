@@ -36,8 +36,8 @@ print(f"wall (100 MHz clock): first block start -> last block end {10 * (rt1.max
 for wv in (0, 4):
     for j in range(8):
         a, b, c_ = tt[:, wv, 145 + 3 * j], tt[:, wv, 146 + 3 * j], tt[:, wv, 147 + 3 * j]
-        if np.median(a) <= 0: break
-        nxt_ = tt[:, wv, 145 + 3 * (j + 1)] if j < 7 and np.median(tt[:, wv, 145 + 3 * (j + 1)]) > 0 else None
+        if not (0 < np.median(b - a) < 1e8 and 0 < np.median(a - tt[:, wv, 170]) < 1e9): break
+        nxt_ = tt[:, wv, 145 + 3 * (j + 1)] if j < 7 and 0 < np.median(tt[:, wv, 145 + 3 * (j + 1)] - c_) < 1e8 else None
         print(f"  wave {wv} tile {j}: start +{np.median(a - tt[:, wv, 170]):8.0f}  K loop {np.median(b - a):7.0f}  epilogue {np.median(c_ - b):7.0f}" + (f"  to next K loop {np.median(nxt_ - c_):6.0f}" if nxt_ is not None else ""))
 for wv in (0, 4):
     e = tt[:, wv, 160:164]; kd = tt[:, wv, 146 + 3]; ed = tt[:, wv, 147 + 3]
