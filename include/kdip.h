@@ -242,6 +242,9 @@ int kdip_debug_conv3_timing(void* dev_buf);
 /* Test / A-B aid: which bf16 3x3 kernel generation runs the large-map convs: 0 = automatic (conv4.hip where a launch has enough
  * 16 x 32-pixel tiles to fill the chip, else conv3.hip), 3 = conv3.hip only, 4 = conv4.hip wherever the shape allows.  Process-wide. */
 int kdip_debug_conv_generation(int gen);
+/* Test / A-B aid: 1 (default) = the large-map bf16 convs compute their GroupNorm staging coefficients from the statistics themselves
+ * (no gn_coef / gn_merge_stats / gn_bwd_coef launches between two convs); 0 = separate coefficient kernels.  Results are bit-identical. */
+int kdip_debug_gn_fold(int on);
 
 #ifdef __cplusplus
 }

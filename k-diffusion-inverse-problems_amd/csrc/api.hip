@@ -477,6 +477,7 @@ int kdip_debug_conv3_timing(void* dev_buf) {      // (either generation's timing
   const int r4 = conv4_debug_timing(dev_buf), r3 = conv3_debug_timing(dev_buf);
   return (r3 && r4) ? r3 : KDIP_OK;
 }
+int kdip_debug_gn_fold(int on) { unet_debug_gn_fold(on); return KDIP_OK; }
 int kdip_debug_conv_generation(int gen) {
   KDIP_REQUIRE(gen == 0 || gen == 3 || gen == 4, "conv generation must be 0 (automatic), 3 or 4");
   conv_debug_generation(gen);

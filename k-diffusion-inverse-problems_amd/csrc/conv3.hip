@@ -204,11 +204,25 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Params p) {
   // per-channel coefficients of the staging transform -> pads of the patch pixels (see c3_tab_off); block-uniform call
   auto load_table = [&](int im) {
     if (TF == 1) {
-      const float4* src = (const float4*)(p.tf_coef + (long)im * p.Cin * 2);
-      for (int j = tid; j < p.Cin / 2; j += 256) *(float4*)(smem + c3_tab_off(j)) = src[j];
+      if (p.fold_stats) {      // coefficients from the statistics (no gn_coef launch in front of this conv); also left in HBM for the VJP
+        const int cpg = p.Cin >> 5;
+        for (int j = tid; j < p.Cin / 2; j += 256) {
+          float4 k; float m0, r0, m1, r1;
+          c3_fold_coef_fwd(p, im, 2 * j, k.x, k.y, m0, r0);
+          c3_fold_coef_fwd(p, im, 2 * j + 1, k.z, k.w, m1, r1);
+          *(float4*)(smem + c3_tab_off(j)) = k;
+          ((float4*)(p.fold_coef_out + (long)im * p.Cin * 2))[j] = k;
+          if ((2 * j) % cpg == 0) *(float2*)(p.fold_mr_out + ((long)im * 32 + (2 * j) / cpg) * 2) = make_float2(m0, r0);
+          if ((2 * j + 1) % cpg == 0) *(float2*)(p.fold_mr_out + ((long)im * 32 + (2 * j + 1) / cpg) * 2) = make_float2(m1, r1);
+        }
+      } else {
+        const float4* src = (const float4*)(p.tf_coef + (long)im * p.Cin * 2);
+        for (int j = tid; j < p.Cin / 2; j += 256) *(float4*)(smem + c3_tab_off(j)) = src[j];
+      }
     } else if (TF == 2) {
       const float4* src = (const float4*)(p.tf_coef + (long)im * p.Cin * 4);
-      for (int j = tid; j < p.Cin; j += 256) *(float4*)(smem + c3_tab_off2((j & ~31) + (j & 7) * 4 + ((j >> 3) & 3))) = src[j];
+      for (int j = tid; j < p.Cin; j += 256)
+        *(float4*)(smem + c3_tab_off2((j & ~31) + (j & 7) * 4 + ((j >> 3) & 3))) = p.fold_stats ? c3_fold_coef_bwd(p, im, j) : src[j];
     }
     tab_img = im;
   };
@@ -807,13 +821,21 @@ int conv3_forward(hipStream_t st, const void* x, long ldx, int B, int H, int W, 
     stm = fu->st_mode; p.st_silu = fu->st_silu; p.st_sums = fu->st_sums; p.st_x = (const bf16_t*)fu->st_x; p.st_ldx = fu->st_ldx;
     p.st_coef = fu->st_coef; p.st_mr = fu->st_mr;
   }
+  if (fu) {
+    p.fold_stats = fu->fold_stats; p.fold_stats2 = fu->fold_stats2; p.fold_C1 = fu->fold_C1; p.fold_gamma = fu->fold_gamma; p.fold_beta = fu->fold_beta;
+    p.fold_film = fu->fold_film; p.fold_film_ld = fu->fold_film_ld ? fu->fold_film_ld : 2L * Cin; p.fold_HW = fu->fold_HW; p.fold_eps = fu->fold_eps;
+    p.fold_coef_out = fu->fold_coef_out; p.fold_mr_out = fu->fold_mr_out; p.fold_coef = fu->fold_coef; p.fold_mr = fu->fold_mr;
+  }
   KDIP_REQUIRE(!(p.in_ups || p.res_ups) || (H % 2 == 0 && W % 2 == 0), "conv3: fused x2 upsample needs even H, W");
 p.dbg = C3_TIMING ? g_c3_dbg : nullptr;
   KDIP_REQUIRE(tf >= 0 && tf <= 2 && stm >= 0 && stm <= 2, "conv3: bad fusion modes");
   // every GroupNorm in front of / behind a 3x3 conv of the UNet is followed by SiLU: the activation is compiled in (a
   // run-time switch doubled the epilogue's register footprint: 170 spilled VGPRs)
   KDIP_REQUIRE((tf == 0 || p.tf_silu) && (stm != 2 || p.st_silu), "conv3: the fused GroupNorm transforms include SiLU");
-  KDIP_REQUIRE(tf == 0 || ((uintptr_t)p.tf_coef % 16) == 0, "conv3: transform coefficients must be 16-byte aligned");
+  KDIP_REQUIRE(tf == 0 || p.fold_stats || (p.tf_coef && ((uintptr_t)p.tf_coef % 16) == 0), "conv3: transform coefficients must be given and 16-byte aligned");
+  KDIP_REQUIRE(!p.fold_stats || (tf == 1 && p.fold_gamma && p.fold_beta && p.fold_coef_out && p.fold_mr_out && p.fold_HW > 0 && (uintptr_t)p.fold_coef_out % 16 == 0 &&
+                                 (!p.fold_stats2 || (p.fold_C1 > 0 && p.fold_C1 < Cin))) ||
+                   (tf == 2 && p.fold_coef && p.fold_mr && p.fold_HW > 0), "conv3: incomplete GroupNorm-coefficient fold");
   KDIP_REQUIRE(tf != 2 || (p.x2 && p.ldx2 == ldx && (uintptr_t)p.x2 % 16 == 0 && !p.in_ups), "conv3: GroupNorm-backward staging needs the GroupNorm input in the layout of x");
   KDIP_REQUIRE(Cin <= c3_max_cin(tf), "conv3: too many input channels (%d) for the staging-transform table", Cin);
   KDIP_REQUIRE((long)H * W * ldx * 2 < (1L << 31), "conv3: image too large for 32-bit staging offsets");

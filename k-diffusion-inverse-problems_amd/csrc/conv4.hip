@@ -190,11 +190,25 @@ __global__ __launch_bounds__(C4_NTHR, 2) void conv4_kernel(Conv3Params p) {
   };
   auto load_table = [&](int im) {
     if (TF == 1) {
-      const float4* src = (const float4*)(p.tf_coef + (long)im * p.Cin * 2);
-      for (int j = tid; j < p.Cin / 2; j += C4_NTHR) *(float4*)(smem + c4_tab_off(j)) = src[j];
+      if (p.fold_stats) {      // coefficients from the statistics (Conv3Fuse::fold_*, as conv3.hip)
+        const int cpg = p.Cin >> 5;
+        for (int j = tid; j < p.Cin / 2; j += C4_NTHR) {
+          float4 k; float m0, r0, m1, r1;
+          c3_fold_coef_fwd(p, im, 2 * j, k.x, k.y, m0, r0);
+          c3_fold_coef_fwd(p, im, 2 * j + 1, k.z, k.w, m1, r1);
+          *(float4*)(smem + c4_tab_off(j)) = k;
+          ((float4*)(p.fold_coef_out + (long)im * p.Cin * 2))[j] = k;
+          if ((2 * j) % cpg == 0) *(float2*)(p.fold_mr_out + ((long)im * 32 + (2 * j) / cpg) * 2) = make_float2(m0, r0);
+          if ((2 * j + 1) % cpg == 0) *(float2*)(p.fold_mr_out + ((long)im * 32 + (2 * j + 1) / cpg) * 2) = make_float2(m1, r1);
+        }
+      } else {
+        const float4* src = (const float4*)(p.tf_coef + (long)im * p.Cin * 2);
+        for (int j = tid; j < p.Cin / 2; j += C4_NTHR) *(float4*)(smem + c4_tab_off(j)) = src[j];
+      }
     } else if (TF == 2) {
       const float4* src = (const float4*)(p.tf_coef + (long)im * p.Cin * 4);
-      for (int j = tid; j < p.Cin; j += C4_NTHR) *(float4*)(smem + c4_tab_off((j & ~31) + (j & 7) * 4 + ((j >> 3) & 3))) = src[j];
+      for (int j = tid; j < p.Cin; j += C4_NTHR)
+        *(float4*)(smem + c4_tab_off((j & ~31) + (j & 7) * 4 + ((j >> 3) & 3))) = p.fold_stats ? c3_fold_coef_bwd(p, im, j) : src[j];
     }
     tab_img = im;
   };

@@ -37,6 +37,17 @@ struct Conv3Fuse {
   int tf = 0, tf_silu = 0;
   const float* tf_coef = nullptr;
   const void* x2 = nullptr; long ldx2 = 0;
+  // GroupNorm-coefficient fold (instead of tf_coef): the conv computes the coefficients while it loads its table, so the tiny
+  // gn_coef / gn_merge_stats / gn_bwd_coef launches leave the dependency chain between two convs.
+  //   tf 1: (a, b) from the input's sums `fold_stats` [B][32][2] (optionally merged on the fly from two producers' sums: channels
+  //         [0, fold_C1) from fold_stats, the rest from fold_stats2), gamma / beta / FiLM rows; written to fold_coef_out [B][Cin][2]
+  //         and fold_mr_out [B][32][2] for the VJP (every block that loads an image's table writes the same values)
+  //   tf 2: (a, b, k0, k1) from fold_coef [B][Cin][2], fold_mr [B][32][2] and the backward sums fold_stats [B][32][2]
+  const double* fold_stats = nullptr; const double* fold_stats2 = nullptr; int fold_C1 = 0;
+  const float *fold_gamma = nullptr, *fold_beta = nullptr, *fold_film = nullptr; long fold_film_ld = 0;
+  long fold_HW = 0; float fold_eps = 1e-5f;
+  float *fold_coef_out = nullptr, *fold_mr_out = nullptr;
+  const float *fold_coef = nullptr, *fold_mr = nullptr;
   // statistics of the OUTPUT accumulated in the epilogue (same meaning as ConvStats::mode 1 / 2); with st_mode 2 the tensor
   // written is dz = dy * silu'(a*st_x + b), NOT dy: run the GroupNorm backward of it with silu = 0
   int st_mode = 0, st_silu = 0;

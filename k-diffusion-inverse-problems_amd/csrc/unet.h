@@ -99,4 +99,6 @@ struct UNet {
   size_t esize() const { return dt == DT_BF16 ? 2 : 4; }
 };
 
+void unet_debug_gn_fold(int on);      // A/B switch of the GroupNorm-coefficient fold (default on)
+
 }  // namespace kdip

@@ -9,6 +9,8 @@
 // weights; GroupNorm/FiLM/SiLU backward = two streaming passes; attention backward = 4
 // batched MFMA GEMMs + a row kernel.
 #include <math.h>
+#include <atomic>
+#include <stdlib.h>
 #include <string.h>
 #include "kernels.h"
 #include "unet.h"
@@ -262,6 +264,9 @@ int UNet::finalize() {
 }
 
 // --------------------------------------------------------------------------- helpers ----
+std::atomic<int> g_gn_fold{[] { const char* e = getenv("KDIP_GN_FOLD"); return e ? (atoi(e) != 0 ? 1 : 0) : 1; }()};      // 1: conv3 / conv4 compute the GroupNorm staging coefficients themselves (no gn_coef / gn_merge_stats / gn_bwd_coef launches)
+void unet_debug_gn_fold(int on) { g_gn_fold.store(on ? 1 : 0); }
+
 namespace {
 struct Ctx {
   UNet* u; hipStream_t st; bool dry; DType dt; size_t es;
@@ -271,8 +276,10 @@ double* new_sums(Ctx& c, int B) { return (double*)c.u->zeros.alloc(sizeof(double
 
 // pool_W > 0: y / pool_x receive the 2x2-average-pooled activated / raw tensors instead (downsampling ResBlock)
 // y == nullptr: statistics + coefficients only (the apply is fused into the consuming conv's input staging, conv3.hip)
+// fold: when given (and y == nullptr: the apply is fused into the consuming conv), NO coefficient kernel is launched either -- the
+// descriptor tells the conv where the statistics, gamma / beta / FiLM rows and the coef / mr output buffers are (Conv3Fuse::fold_*)
 int gn_forward(Ctx& c, const void* x, long ldx, int B, long HW, const GnW& g, const float* film, int silu, void* y,
-               long ldy, float** coef_out, float** mr_out, long film_ld = 0, int pool_W = 0, void* pool_x = nullptr) {
+               long ldy, float** coef_out, float** mr_out, long film_ld = 0, int pool_W = 0, void* pool_x = nullptr, Conv3Fuse* fold = nullptr) {
   bool dry = c.dry;
   float* coef = (float*)c.u->persist.alloc(sizeof(float) * B * g.C * 2);
   float* mr = (float*)c.u->persist.alloc(sizeof(float) * B * 64);
@@ -281,7 +288,9 @@ int gn_forward(Ctx& c, const void* x, long ldx, int B, long HW, const GnW& g, co
     RUN(gn_fwd_small(c.st, c.dt, x, ldx, B, HW, g.C, g.gamma, g.beta, film, film_ld, 1e-5f, silu, y, ldy, coef, mr));
     return KDIP_OK;
   }
+  const bool do_fold = fold && !y && g_gn_fold.load();
   double* stats = nullptr;
+  const double* stats2 = nullptr; int mC1 = 0;          // do_fold: un-merged sums of the two producers of a concat
   auto it = c.u->fused_stats.find(std::make_pair(x, g.C));
   if (it != c.u->fused_stats.end()) stats = it->second;                      // accumulated by the producing conv
   if (!stats && ldx == g.C) {
@@ -291,6 +300,7 @@ int gn_forward(Ctx& c, const void* x, long ldx, int B, long HW, const GnW& g, co
       if (C2 <= 0 || !gn_merge_eligible(C1, C2)) continue;
       auto hi = c.u->fused_stats.find(std::make_pair((const void*)((const char*)x + c.es * C1), C2));
       if (hi == c.u->fused_stats.end()) continue;
+      if (do_fold) { stats = lo->second; stats2 = hi->second; mC1 = C1; break; }      // merged by the conv while it loads its table
       stats = new_sums(c, B);
       RUN(gn_merge_stats(c.st, lo->second, C1, hi->second, C2, B, stats));
       break;
@@ -299,6 +309,12 @@ int gn_forward(Ctx& c, const void* x, long ldx, int B, long HW, const GnW& g, co
   if (!stats) {
     stats = new_sums(c, B);
     RUN(gn_stats(c.st, c.dt, x, ldx, B, HW, g.C, stats, 1));
+  }
+  if (do_fold) {
+    fold->fold_stats = stats; fold->fold_stats2 = stats2; fold->fold_C1 = mC1; fold->fold_gamma = g.gamma; fold->fold_beta = g.beta;
+    fold->fold_film = film; fold->fold_film_ld = film_ld; fold->fold_HW = HW; fold->fold_eps = 1e-5f;
+    fold->fold_coef_out = coef; fold->fold_mr_out = mr;
+    return KDIP_OK;
   }
   RUN(gn_coef(c.st, stats, g.gamma, g.beta, film, B, HW, g.C, 1e-5f, coef, mr, film_ld));
   if (!y) return KDIP_OK;
@@ -353,13 +369,19 @@ bool use_conv3(Ctx& c, const ConvW& w, int B, int H, int W, long ldx, long ldy, 
 // tf_coef: the input is a GroupNorm INPUT and (a, b) [B][cin][2] are its coefficients: silu(a*x + b) is applied while the
 // patch is staged (only when use_conv3())
 int conv_f(Ctx& c, const ConvW& w, const void* x, long ldx, int B, int H, int W, void* y, long ldy, const void* res,
-           long ldr, int out_f32, bool fuse_out_stats = false, int in_ups = 0, int res_ups = 0, const float* tf_coef = nullptr) {
+           long ldr, int out_f32, bool fuse_out_stats = false, int in_ups = 0, int res_ups = 0, const float* tf_coef = nullptr,
+           const Conv3Fuse* fold = nullptr) {
   bool dry = c.dry;
   const bool stats_ok = fuse_out_stats && !out_f32 && conv_stats_eligible(H, W, w.cout) && !gn_small_eligible(c.dt, (long)H * W, w.cout);
   if (use_conv3(c, w, B, H, W, ldx, ldy, false, out_f32, tf_coef ? 1 : 0)) {
     Conv3Fuse fu;
     fu.in_ups = in_ups; fu.res_ups = res_ups;
     if (tf_coef) { fu.tf = 1; fu.tf_silu = 1; fu.tf_coef = tf_coef; }
+    if (tf_coef && fold && fold->fold_stats) {      // the conv computes (and stores) the coefficients itself
+      fu.fold_stats = fold->fold_stats; fu.fold_stats2 = fold->fold_stats2; fu.fold_C1 = fold->fold_C1; fu.fold_gamma = fold->fold_gamma;
+      fu.fold_beta = fold->fold_beta; fu.fold_film = fold->fold_film; fu.fold_film_ld = fold->fold_film_ld; fu.fold_HW = fold->fold_HW;
+      fu.fold_eps = fold->fold_eps; fu.fold_coef_out = fold->fold_coef_out; fu.fold_mr_out = fold->fold_mr_out;
+    }
     if (stats_ok) {
       fu.st_mode = 1;
       fu.st_sums = new_sums(c, B);
@@ -388,7 +410,7 @@ int conv_f(Ctx& c, const ConvW& w, const void* x, long ldx, int B, int H, int W,
 int conv_b(Ctx& c, const ConvW& w, const void* g, long ldg, int B, int H, int W, void* y, long ldy, const void* res,
            long ldr, int out_f32, const void* gn_x = nullptr, long gn_ldx = 0, const float* gn_coef = nullptr,
            const float* gn_mr = nullptr, int gn_silu = 0, double** sums_out = nullptr, const float* tf2_coef = nullptr,
-           const void* tf2_x2 = nullptr, int* y_is_dz = nullptr) {
+           const void* tf2_x2 = nullptr, int* y_is_dz = nullptr, const Conv3Fuse* fold2 = nullptr) {
   bool dry = c.dry;
   if (sums_out) *sums_out = nullptr;
   if (y_is_dz) *y_is_dz = 0;          // 1: y holds dz = dy * silu'(z) of the GroupNorm (gn_x, gn_coef): apply its backward with silu = 0
@@ -396,6 +418,9 @@ int conv_b(Ctx& c, const ConvW& w, const void* g, long ldg, int B, int H, int W,
   if (use_conv3(c, w, B, H, W, ldg, ldy, true, out_f32, tf2_coef ? 2 : 0) && !res && (!stats_ok || (gn_silu && y_is_dz))) {
     Conv3Fuse fu;
     if (tf2_coef) { fu.tf = 2; fu.tf_silu = 1; fu.tf_coef = tf2_coef; fu.x2 = tf2_x2; fu.ldx2 = ldg; }
+    if (tf2_coef && fold2 && fold2->fold_stats) {   // (a, b, k0, k1) computed by the conv from coef / mr / backward sums: no gn_bwd_coef launch
+      fu.fold_stats = fold2->fold_stats; fu.fold_coef = fold2->fold_coef; fu.fold_mr = fold2->fold_mr; fu.fold_HW = fold2->fold_HW;
+    }
     if (stats_ok) {
       fu.st_mode = 2; fu.st_silu = 1; fu.st_x = gn_x; fu.st_ldx = gn_ldx; fu.st_coef = gn_coef; fu.st_mr = gn_mr;
       fu.st_sums = new_sums(c, B);
@@ -473,7 +498,8 @@ static int res_forward(Ctx& c, Layer& L, const void* x, long ldx, int B, int& H,
   const bool f1 = L.mode != 1 && use_conv3(c, L.c1, B, Ho, Wo, ldx, L.cout, false, 0, 1) && (L.mode != 2 || !gn_small_eligible(c.dt, HW, L.cin));
   const bool f2 = use_conv3(c, L.c2, B, Ho, Wo, L.cout, ldo, false, 0, 1);
   void* h1 = (fused_pool || f1) ? nullptr : u->scratch.alloc(es * B * HW * L.cin);
-  if (!fused_pool) CK(gn_forward(c, x, ldx, B, HW, L.n1, nullptr, 1, h1, L.cin, &L.sv.coef1, &L.sv.mr1));
+  Conv3Fuse fold1, fold2;                              // GroupNorm-coefficient folds of conv1 / conv2 (filled when the apply is fused)
+  if (!fused_pool) CK(gn_forward(c, x, ldx, B, HW, L.n1, nullptr, 1, h1, L.cin, &L.sv.coef1, &L.sv.mr1, 0, 0, nullptr, f1 ? &fold1 : nullptr));
   const void* cin_ptr = h1; const void* xs = x; long ldxs = ldx;
   if (L.mode == 1) {
     void* h1p = u->scratch.alloc(es * B * Ho * Wo * L.cin);
@@ -490,11 +516,11 @@ static int res_forward(Ctx& c, Layer& L, const void* x, long ldx, int B, int& H,
   // skip path read the half-resolution tensors at (y >> 1, x >> 1); no 4x-sized copies are written or re-read)
   void* h2 = u->persist.alloc(es * B * HWo * L.cout);
   L.sv.h2 = h2;
-  if (f1) CK(conv_f(c, L.c1, x, ldx, B, Ho, Wo, h2, L.cout, nullptr, 0, 0, true, ups, 0, L.sv.coef1));
+  if (f1) CK(conv_f(c, L.c1, x, ldx, B, Ho, Wo, h2, L.cout, nullptr, 0, 0, true, ups, 0, L.sv.coef1, &fold1));
   else CK(conv_f(c, L.c1, cin_ptr, L.cin, B, Ho, Wo, h2, L.cout, nullptr, 0, 0, true, ups, 0));
   const float* film = film_all + L.emb_off;          // row b at film + b * emb_total
   void* h3 = f2 ? nullptr : u->scratch.alloc(es * B * HWo * L.cout);
-  CK(gn_forward(c, h2, L.cout, B, HWo, L.n2, film, 1, h3, L.cout, &L.sv.coef2, &L.sv.mr2, u->emb_total));
+  CK(gn_forward(c, h2, L.cout, B, HWo, L.n2, film, 1, h3, L.cout, &L.sv.coef2, &L.sv.mr2, u->emb_total, 0, nullptr, f2 ? &fold2 : nullptr));
   const void* S = xs; long ldS = ldxs;
   if (L.has_skip) {
     void* sk = u->scratch.alloc(es * B * HWo * L.cout);
@@ -502,7 +528,7 @@ static int res_forward(Ctx& c, Layer& L, const void* x, long ldx, int B, int& H,
     S = sk; ldS = L.cout;
   }
   const int rups = (ups && !L.has_skip) ? 1 : 0;
-  if (f2) CK(conv_f(c, L.c2, h2, L.cout, B, Ho, Wo, o, ldo, S, ldS, 0, true, 0, rups, L.sv.coef2));
+  if (f2) CK(conv_f(c, L.c2, h2, L.cout, B, Ho, Wo, o, ldo, S, ldS, 0, true, 0, rups, L.sv.coef2, &fold2));
   else CK(conv_f(c, L.c2, h3, L.cout, B, Ho, Wo, o, ldo, S, ldS, 0, true, 0, rups));
   *outp = o; H = Ho; W = Wo;
   return KDIP_OK;
@@ -689,9 +715,11 @@ static int res_backward(Ctx& c, Layer& L, const void* G, long ldG, void** gxp, c
   const bool fb = sums2 && g3_dz && use_conv3(c, L.c1, B, Ho, Wo, L.cout, L.cin, true, 0, 2);
   const void* gh2 = nullptr;
   float* tf2 = nullptr;
+  Conv3Fuse foldb;
   if (fb) {
     tf2 = (float*)u->scratch.alloc(sizeof(float) * B * L.cout * 4);
-    RUN(gn_bwd_coef(c.st, L.sv.coef2, L.sv.mr2, sums2, B, HWo, L.cout, tf2));
+    if (g_gn_fold.load()) { foldb.fold_stats = sums2; foldb.fold_coef = L.sv.coef2; foldb.fold_mr = L.sv.mr2; foldb.fold_HW = HWo; }
+    else RUN(gn_bwd_coef(c.st, L.sv.coef2, L.sv.mr2, sums2, B, HWo, L.cout, tf2));
   } else {
     void* t = u->scratch.alloc(es * B * HWo * L.cout);
     CK(gn_backward(c, L.sv.h2, L.cout, g3, L.cout, L.sv.coef2, L.sv.mr2, B, HWo, L.cout, g3_dz ? 0 : 1, nullptr, 0, t, L.cout, sums2));
@@ -699,9 +727,9 @@ static int res_backward(Ctx& c, Layer& L, const void* G, long ldG, void** gxp, c
   }
   int g1_dz = 0;
   if (L.mode == 0)
-    CK(conv_b(c, L.c1, fb ? g3 : gh2, L.cout, B, Ho, Wo, g1p, L.cin, nullptr, 0, 0, L.sv.x, L.sv.ldx, L.sv.coef1, L.sv.mr1, 1, &sums1, tf2, fb ? L.sv.h2 : nullptr, &g1_dz));
+    CK(conv_b(c, L.c1, fb ? g3 : gh2, L.cout, B, Ho, Wo, g1p, L.cin, nullptr, 0, 0, L.sv.x, L.sv.ldx, L.sv.coef1, L.sv.mr1, 1, &sums1, tf2, fb ? L.sv.h2 : nullptr, &g1_dz, &foldb));
   else
-    CK(conv_b(c, L.c1, fb ? g3 : gh2, L.cout, B, Ho, Wo, g1p, L.cin, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, 0, nullptr, tf2, fb ? L.sv.h2 : nullptr));
+    CK(conv_b(c, L.c1, fb ? g3 : gh2, L.cout, B, Ho, Wo, g1p, L.cin, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, 0, nullptr, tf2, fb ? L.sv.h2 : nullptr, nullptr, &foldb));
   // skip path: grad wrt (resampled) x
   const void* gS = G; long ldgS = ldG;
   if (L.has_skip) {

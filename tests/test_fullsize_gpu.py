@@ -248,3 +248,35 @@ def test_unet_vjp_properties_fullsize():
     rel = float(((lhs - rhs).abs() / rhs.abs().clamp_min(1e-6)).max())
     print(f"\nVJP linearity {lin:.1e}; directional derivative rel err {rel:.2e} (lhs {lhs.tolist()}, rhs {rhs.tolist()})")
     assert rel < 5e-3, (lhs, rhs)
+
+
+def test_gn_coefficient_fold_bit_identical():
+    """The large-map bf16 convs compute their GroupNorm staging coefficients from the statistics themselves (Conv3Fuse::fold_*: no
+    gn_coef / gn_merge_stats / gn_bwd_coef launch between two convs).  Same arithmetic as the separate kernels: UNet forward and
+    input-VJP at the FFHQ shape, batch 2, with the fold on and off, agree to the run-to-run noise of the fp64 statistics atomics
+    (and the coefficients the VJP reads back are the ones the convs wrote)."""
+    import kdip_amd._lib as L
+    import kdip_amd.unet as ku
+    lib = L.load()
+    sd = ku.synthetic_state_dict(seed=0, **ku.FFHQ_CONFIG)
+    m = ku.UNetModel(dtype="bf16", **ku.FFHQ_CONFIG)
+    m.load_state_dict(sd)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 3, 256, 256, generator=g).cuda()
+    t = torch.tensor([321.0, 321.0]).cuda()
+    cot = torch.randn(2, 6, 256, 256, generator=g).cuda()
+    res = {}
+    try:
+        for on in (1, 0, 1):
+            L.check(lib.kdip_debug_gn_fold(on))
+            out, _, _ = m.forward_raw(x, t, in_scale=0.7)
+            res.setdefault(on, []).append((out.clone(), m.vjp(cot).clone()))
+    finally:
+        L.check(lib.kdip_debug_gn_fold(1))
+    noise_o = float((res[1][0][0] - res[1][1][0]).abs().max())          # two runs of the SAME mode: atomics-order noise
+    noise_g = float((res[1][0][1] - res[1][1][1]).abs().max())
+    d_o = float((res[1][0][0] - res[0][0][0]).abs().max())
+    d_g = float((res[1][0][1] - res[0][0][1]).abs().max())
+    so, sg = float(res[0][0][0].abs().max()), float(res[0][0][1].abs().max())
+    print(f"\nfold on vs off: out {d_o:.3e} (same-mode noise {noise_o:.3e}, scale {so:.2f}); vjp {d_g:.3e} (noise {noise_g:.3e}, scale {sg:.2f})")
+    assert d_o <= max(4 * noise_o, 2e-2 * so) and d_g <= max(4 * noise_g, 2e-2 * sg)
