@@ -258,15 +258,15 @@ def main():
         key, (cnt, us, gf, mb) = max(grp.items(), key=lambda kv: kv[1][1])
         tflops = gf / us * 1e3 if us > 0 else 0.0          # GFLOP / us = PFLOP/s
         # HBM traffic of this (kernel, fusion mode, layer shape): rocprofv3 --pmc passes over the same in-network launches
-        # (tools/pmc_innetwork.sh -> profiles/r02_pmc_innetwork.json; FETCH_SIZE x 2 + WRITE_SIZE per MI355X_MICROARCH.md)
+        # (tools/pmc_innetwork.sh -> profiles/r03_pmc_innetwork.json; FETCH_SIZE x 2 + WRITE_SIZE per MI355X_MICROARCH.md)
         traffic, traffic_source, pmc_extra = None, None, {}
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_innetwork.json")
-        if os.path.exists(pmc):
+        pmc = next((f for f in (os.path.join(ROOT, "profiles", t + "_pmc_innetwork.json") for t in ("r03", "r02")) if os.path.exists(f)), "")
+        if pmc:
             try:
                 e = json.load(open(pmc))["shapes"].get("|".join(key[1:]))
                 if e:
                     traffic = e.get("hbm_bytes_per_launch")
-                    traffic_source = ("profiles/r02_pmc_innetwork.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the in-network launches "
+                    traffic_source = ("profiles/" + os.path.basename(pmc) + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the in-network launches "
                                       "of this kernel + fusion mode + layer shape (tools/pmc_innetwork.sh on one guided Heun step of this workload); "
                                       "not re-measured in this run")
                     pmc_extra = {k: e[k] for k in ("traffic_over_algorithmic", "mfma_busy_frac", "shader_clock_ghz", "lds_bank_conflict_frac_of_lds_active",

@@ -13,6 +13,18 @@ struct kdip_unet { UNet u; };
 struct kdip_op { OpCtx c; };
 
 #define API_CK(call) do { int _rc = (call); if (_rc) return _rc; } while (0)
+namespace {
+// device buffers of a test hook: freed on every return path
+struct DevPool {
+  std::vector<void*> bufs;
+  ~DevPool() { for (void* b : bufs) (void)hipFree(b); }
+  int get(void** out, size_t bytes) {
+    if (hipMalloc(out, bytes) != hipSuccess) return kdip::set_error(KDIP_ERR_NOMEM, "test hook: hipMalloc(%zu) failed", bytes);
+    bufs.push_back(*out);
+    return KDIP_OK;
+  }
+};
+}  // namespace
 #define ST(s) ((hipStream_t)(s))
 
 extern "C" {
@@ -406,17 +418,16 @@ int kdip_test_attention(void* stream, const float* qkv_dev, const float* dO_dev,
   const int C = heads * 64;
   const size_t nq = (size_t)B * T * 3 * C, no = (size_t)B * T * C;
   void *qkv = nullptr, *dO = nullptr, *o = nullptr, *dq = nullptr, *ws = nullptr; float *lse = nullptr, *D = nullptr;
-  KDIP_HIP_CHECK(hipMalloc(&qkv, 2 * nq)); KDIP_HIP_CHECK(hipMalloc(&dO, 2 * no)); KDIP_HIP_CHECK(hipMalloc(&o, 2 * no));
-  KDIP_HIP_CHECK(hipMalloc(&dq, 2 * nq)); KDIP_HIP_CHECK(hipMalloc(&ws, 2 * no * 3));
-  KDIP_HIP_CHECK(hipMalloc((void**)&lse, sizeof(float) * B * heads * T)); KDIP_HIP_CHECK(hipMalloc((void**)&D, sizeof(float) * B * heads * T));
+  DevPool pool;
+  API_CK(pool.get(&qkv, 2 * nq)); API_CK(pool.get(&dO, 2 * no)); API_CK(pool.get(&o, 2 * no)); API_CK(pool.get(&dq, 2 * nq));
+  API_CK(pool.get(&ws, 2 * no * 3)); API_CK(pool.get((void**)&lse, sizeof(float) * B * heads * T)); API_CK(pool.get((void**)&D, sizeof(float) * B * heads * T));
   int rc = f32_to_bf16(st, qkv_dev, (long)nq, qkv);
   if (!rc) rc = f32_to_bf16(st, dO_dev, (long)no, dO);
   if (!rc) rc = attn_fused_forward(st, qkv, 3 * C, B, T, heads, ws, o, C, lse);
   if (!rc) rc = attn_fused_backward(st, qkv, 3 * C, dO, C, o, C, lse, B, T, heads, ws, D, dq, 3 * C);
   if (!rc) rc = T_to_f32(st, DT_BF16, o, (long)no, o_dev);
   if (!rc) rc = T_to_f32(st, DT_BF16, dq, (long)nq, dqkv_dev);
-  hipError_t e = hipStreamSynchronize(st);
-  (void)hipFree(qkv); (void)hipFree(dO); (void)hipFree(o); (void)hipFree(dq); (void)hipFree(ws); (void)hipFree(lse); (void)hipFree(D);
+  hipError_t e = hipStreamSynchronize(st);         // (the pool frees after the stream has drained)
   if (rc) return rc;
   KDIP_HIP_CHECK(e);
   return KDIP_OK;
@@ -439,15 +450,16 @@ int kdip_test_conv3(void* stream, const float* x_nchw, const float* x2_nchw, int
   pack_conv_weight(dt, w_host, Cout, Cin, 9, transpose_flip, cpad, buf.data());
   void *wp = nullptr, *xin = nullptr, *x2 = nullptr, *res = nullptr, *stx = nullptr, *ys = nullptr; float* bias = nullptr;
   const int Hi = in_ups ? H / 2 : H, Wi = in_ups ? W / 2 : W, Hr = res_ups ? H / 2 : H, Wr = res_ups ? W / 2 : W;
-  KDIP_HIP_CHECK(hipMalloc(&wp, buf.size()));
+  DevPool pool;
+  API_CK(pool.get(&wp, buf.size()));
   KDIP_HIP_CHECK(hipMemcpy(wp, buf.data(), buf.size(), hipMemcpyHostToDevice));
-  if (bias_host) { KDIP_HIP_CHECK(hipMalloc((void**)&bias, sizeof(float) * Co)); KDIP_HIP_CHECK(hipMemcpy(bias, bias_host, sizeof(float) * Co, hipMemcpyHostToDevice)); }
-  KDIP_HIP_CHECK(hipMalloc(&xin, es * (size_t)B * Hi * Wi * cpad));
-  KDIP_HIP_CHECK(hipMalloc(&ys, es * (size_t)B * H * W * Co));
+  if (bias_host) { API_CK(pool.get((void**)&bias, sizeof(float) * Co)); KDIP_HIP_CHECK(hipMemcpy(bias, bias_host, sizeof(float) * Co, hipMemcpyHostToDevice)); }
+  API_CK(pool.get(&xin, es * (size_t)B * Hi * Wi * cpad));
+  API_CK(pool.get(&ys, es * (size_t)B * H * W * Co));
   int rc = nchw_to_nhwc(st, dt, x_nchw, B, Ci, Hi, Wi, 1.f, xin, cpad, cpad);
-  if (x2_nchw) { KDIP_HIP_CHECK(hipMalloc(&x2, es * (size_t)B * H * W * cpad)); if (!rc) rc = nchw_to_nhwc(st, dt, x2_nchw, B, Ci, H, W, 1.f, x2, cpad, cpad); }
-  if (res_nchw) { KDIP_HIP_CHECK(hipMalloc(&res, es * (size_t)B * Hr * Wr * Co)); if (!rc) rc = nchw_to_nhwc(st, dt, res_nchw, B, Co, Hr, Wr, 1.f, res, Co, Co); }
-  if (stx_nchw) { KDIP_HIP_CHECK(hipMalloc(&stx, es * (size_t)B * H * W * Co)); if (!rc) rc = nchw_to_nhwc(st, dt, stx_nchw, B, Co, H, W, 1.f, stx, Co, Co); }
+  if (x2_nchw) { API_CK(pool.get(&x2, es * (size_t)B * H * W * cpad)); if (!rc) rc = nchw_to_nhwc(st, dt, x2_nchw, B, Ci, H, W, 1.f, x2, cpad, cpad); }
+  if (res_nchw) { API_CK(pool.get(&res, es * (size_t)B * Hr * Wr * Co)); if (!rc) rc = nchw_to_nhwc(st, dt, res_nchw, B, Co, Hr, Wr, 1.f, res, Co, Co); }
+  if (stx_nchw) { API_CK(pool.get(&stx, es * (size_t)B * H * W * Co)); if (!rc) rc = nchw_to_nhwc(st, dt, stx_nchw, B, Co, H, W, 1.f, stx, Co, Co); }
   Conv3Fuse fu;
   fu.in_ups = in_ups; fu.res_ups = res_ups; fu.tf = tf; fu.tf_silu = 1; fu.tf_coef = tf_coef_dev; fu.x2 = x2; fu.ldx2 = cpad;
   fu.st_mode = st_mode; fu.st_silu = 1; fu.st_sums = sums_dev; fu.st_x = stx; fu.st_ldx = Co; fu.st_coef = st_coef_dev; fu.st_mr = st_mr_dev;
@@ -467,7 +479,6 @@ int kdip_test_conv3(void* stream, const float* x_nchw, const float* x2_nchw, int
   if (!rc) rc = nhwc_T_to_nchw_f32(st, dt, ys, Co, B, Co, H, W, y_nchw);
   hipError_t e = hipStreamSynchronize(st);
   if (e0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
-  (void)hipFree(wp); (void)hipFree(xin); (void)hipFree(ys); if (x2) (void)hipFree(x2); if (res) (void)hipFree(res); if (stx) (void)hipFree(stx); if (bias) (void)hipFree(bias);
   if (rc) return rc;
   KDIP_HIP_CHECK(e);
   return KDIP_OK;
