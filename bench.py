@@ -113,6 +113,61 @@ def cpu_baseline(sig):
                       "branch), extrapolated to 157 + 42 calls = 100 Heun steps" % (float(sig[10]), float(sig[95]))}
 
 
+class PowerSampler:
+    """rocm-smi package power / shader clock beside the timed region (rank 0): the workload runs the chip at its power limit, so
+    the clock the MFMA peak is quoted at (2.4 GHz) is not the clock the kernels get.  Best effort: absent tool or
+    unparsable output -> no `power` object."""
+
+    def __init__(self, period=0.4):
+        import threading
+        self.period, self.samples, self._stop = period, [], threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self):
+        import subprocess
+        r = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=10)
+        card = next(iter(json.loads(r.stdout[r.stdout.index("{"):]).values()))
+        pw = next((float(v) for k, v in card.items() if "Power (W)" in k), None)
+        sc = next((v for k, v in card.items() if k.startswith("sclk clock speed")), None)
+        mhz = float(sc.strip("()").lower().replace("mhz", "")) if sc else None
+        return pw, mhz
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                self.samples.append(self._read())
+            except Exception:
+                pass
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        self._th.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        self._th.join(timeout=15)
+
+    def summary(self):
+        import subprocess
+        pw = sorted(p for p, _ in self.samples if p)
+        ck = sorted(c for _, c in self.samples if c)
+        if len(pw) < 3:
+            return None
+        pw, ck = pw[len(pw) // 4:], ck[len(ck) // 4:] if len(ck) > 3 else ck      # (drop the ramp-up quarter: lowest samples)
+        out = {"package_power_w_median": pw[len(pw) // 2], "package_power_w_max": pw[-1], "samples": len(self.samples),
+               "source": "rocm-smi --showpower --showclocks polled beside the timed region"}
+        if ck:
+            out["shader_clock_mhz_median"] = sorted(ck)[len(ck) // 2]
+        try:
+            r = subprocess.run(["rocm-smi", "--showmaxpower", "--json"], capture_output=True, text=True, timeout=10)
+            card = next(iter(json.loads(r.stdout[r.stdout.index("{"):]).values()))
+            out["package_power_cap_w"] = next(float(v) for k, v in card.items() if "Power" in k)
+        except Exception:
+            pass
+        return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -217,7 +272,12 @@ def main():
     idx = step_indices(args.steps)
     parts = build_parts(B, args.streams)
     S_ = len(parts)
-    elapsed = timed_run(parts, idx, full_run, args.warmup)
+    sampler = PowerSampler() if env.is_main_process else None
+    if sampler:
+        with sampler:
+            elapsed = timed_run(parts, idx, full_run, args.warmup)
+    else:
+        elapsed = timed_run(parts, idx, full_run, args.warmup)
     den, x0 = parts[0]["den"], parts[0]["x0"]             # the roofline leg profiles part 0 alone
 
     ms_per_step = elapsed / args.steps * 1e3
@@ -235,6 +295,9 @@ def main():
                    "parallelism": f"dp{env.world_size} (independent images, one all_gather at the end)"},
         "achieved_tflops_whole_step": round(2 * B * FWD_VJP_GFLOP_PER_IMAGE_CALL / ms_per_step, 2),
     }
+    pw = sampler.summary() if sampler else None
+    if pw:
+        out["power"] = pw
 
     # ---- roofline leg: per-launch HIP-event timing of the conv kernels on two representative steps
     if not args.no_roofline and env.is_main_process:
