@@ -102,6 +102,10 @@ def load():
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python k-diffusion-inverse-problems_amd/build.py` "
             "(or __graft_entry__.build()).  kdip_amd has no CPU / PyTorch fallback.")
+    # PyTorch-ROCm bundles its own libamdhip64: it has to be in the process BEFORE libkdip_hip.so is loaded, so that the library's
+    # libamdhip64.so.7 dependency resolves to the runtime torch allocates with.  Loaded first, the library binds the system runtime
+    # instead and the process ends up with two HIP runtimes (the second one reports "no ROCm-capable device").
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError if the symbol is missing
