@@ -272,7 +272,7 @@ def main():
     idx = step_indices(args.steps)
     parts = build_parts(B, args.streams)
     S_ = len(parts)
-    sampler = PowerSampler() if env.is_main_process else None
+    sampler = PowerSampler() if env.is_main_process and not os.environ.get("KDIP_NO_POWER") else None
     if sampler:
         with sampler:
             elapsed = timed_run(parts, idx, full_run, args.warmup)
