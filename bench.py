@@ -202,6 +202,8 @@ def main():
     sigmas = ks.get_sigmas_karras(100, 0.01, 80, rho=7.0, device=dev)
     sig = sigmas.detach().cpu()
     sd = ku.synthetic_state_dict(seed=0, **ku.FFHQ_CONFIG)      # random-init weights of the named architecture (no checkpoint offline)
+    if os.environ.get("KDIP_EXP_ZERO_WEIGHTS"):                  # diagnostic only: identical instruction stream on all-zero conv weights
+        sd = {k: (v * 0 if k.endswith("weight") and v.dim() == 4 else v) for k, v in sd.items()}
 
     # ---- the per-GPU batch is split into `--streams` part-batches, each with its own UNet handle (weights + workspace),
     # operator context, HIP stream and host thread: images are independent problems, so while one part is in its
