@@ -177,7 +177,8 @@ def main():
     ap.add_argument("--no-large-batch", action="store_true", help="skip the extra throughput leg at batch 128 (N = 1 only)")
     ap.add_argument("--streams", type=int, default=2, help="part-batches per GPU, each on its own HIP stream + host thread")
     ap.add_argument("--cu-split", action="store_true", help="give each part-batch stream its own share of the compute units (CU-masked HIP streams)")
-    ap.add_argument("--dtype", choices=("bf16", "f32"), default="bf16", help="UNet storage / MFMA type (f32 = the exact-f32 parity mode)")
+    ap.add_argument("--dtype", choices=("bf16", "f32", "bf16x3"), default="bf16",
+                    help="UNet storage / MFMA type (f32 = the exact-f32 parity mode; bf16x3 = fp32 storage + split-bf16 convs, the fast tolerance-compliant mode)")
     ap.add_argument("--no-graph-leg", action="store_true", help="skip the extra leg that replays the guided calls from hipGraphs (N = 1 only)")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the extra leg that times the same workload in the f32 parity mode (N = 1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

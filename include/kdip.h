@@ -27,7 +27,10 @@ extern "C" {
 
 enum { KDIP_OK = 0, KDIP_ERR_ARG = -1, KDIP_ERR_HIP = -2, KDIP_ERR_STATE = -3, KDIP_ERR_NOMEM = -4,
        KDIP_ERR_UNSUPPORTED = -5 };
-enum { KDIP_F32 = 0, KDIP_BF16 = 1 };                 /* storage / MFMA input type of the UNet */
+enum { KDIP_F32 = 0, KDIP_BF16 = 1,                   /* storage / MFMA input type of the UNet */
+       KDIP_BF16X3 = 2 };   /* fp32 storage, split-precision convs: operands = bf16 hi + bf16 lo, hi*hi + hi*lo + lo*hi on the bf16
+                             * MFMA with fp32 accumulation (operand error ~2^-17 instead of 2^-9): the fast mode that meets the
+                             * 1e-3 dB tolerance against the reference's fp32 arithmetic (utils_model.py:364 use_fp16=False) */
 enum { KDIP_OP_INPAINT = 0, KDIP_OP_BLUR = 1, KDIP_OP_SR = 2 };
 enum { KDIP_OT_NONE = 0, KDIP_OT_DWT = 1, KDIP_OT_DCT = 2 };
 

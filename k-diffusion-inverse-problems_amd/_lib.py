@@ -82,7 +82,8 @@ SIGNATURES = {
     "kdip_test_groupnorm": (C.c_int, [VP, C.c_int, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, VP, C.c_int, VP, VP, VP]),
 }
 
-F32, BF16 = 0, 1
+F32, BF16, BF16X3 = 0, 1, 2
+DTYPES = {"f32": F32, "bf16": BF16, "bf16x3": BF16X3}      # include/kdip.h: KDIP_F32 / KDIP_BF16 / KDIP_BF16X3
 OP_INPAINT, OP_BLUR, OP_SR = 0, 1, 2
 OT_NONE, OT_DWT, OT_DCT = 0, 1, 2
 

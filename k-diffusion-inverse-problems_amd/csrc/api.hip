@@ -37,7 +37,7 @@ int kdip_unet_create(int device, int dtype, int image_size, int in_channels, int
                      int num_res_blocks, const int* attention_ds, int n_attention_ds, const int* channel_mult,
                      int n_channel_mult, int num_head_channels, kdip_unet** out) {
   KDIP_REQUIRE(out, "null output handle");
-  KDIP_REQUIRE(dtype == KDIP_F32 || dtype == KDIP_BF16, "dtype %d", dtype);
+  KDIP_REQUIRE(dtype == KDIP_F32 || dtype == KDIP_BF16 || dtype == KDIP_BF16X3, "dtype %d", dtype);
   KDIP_REQUIRE(in_channels == 3 && out_channels <= 32, "in_channels must be 3, out_channels <= 32");
   KDIP_REQUIRE(model_channels % 32 == 0, "model_channels must be a multiple of 32");
   int ndev = 0;
@@ -46,6 +46,7 @@ int kdip_unet_create(int device, int dtype, int image_size, int in_channels, int
   kdip_unet* h = new kdip_unet();
   h->u.device = device;
   h->u.dt = dtype == KDIP_BF16 ? DT_BF16 : DT_F32;
+  h->u.cdt = dtype == KDIP_BF16X3 ? DT_F32X3 : h->u.dt;
   h->u.cfg.image_size = image_size; h->u.cfg.in_channels = in_channels; h->u.cfg.model_channels = model_channels;
   h->u.cfg.out_channels = out_channels; h->u.cfg.num_res_blocks = num_res_blocks;
   h->u.cfg.attention_ds.assign(attention_ds, attention_ds + n_attention_ds);
@@ -326,13 +327,14 @@ int kdip_debug_conv_timing(void* dev_buf, int H, int cin, int cout, int st_mode)
 int kdip_test_conv(void* stream, int dtype, int ntaps, const float* x_nchw, int B, int Cin, int H, int W, const float* w_host,
                    const float* bias_host, int Cout, int transpose_flip, float* y_nchw, int storage_out) {
   hipStream_t st = ST(stream);
-  DType dt = dtype == KDIP_BF16 ? DT_BF16 : DT_F32;
+  const DType cdt = dtype == KDIP_BF16 ? DT_BF16 : (dtype == KDIP_BF16X3 ? DT_F32X3 : DT_F32);      // conv arithmetic
+  const DType dt = storage_dtype(cdt);
   size_t es = dt == DT_BF16 ? 2 : 4;
   // logical conv after optional transpose: Ci -> Co
   const int Ci = transpose_flip ? Cout : Cin, Co = transpose_flip ? Cin : Cout;
   const int cpad = pad32i(Ci);
-  std::vector<char> buf(packed_weight_bytes(dt, ntaps, cpad, Co));
-  pack_conv_weight(dt, w_host, Cout, Cin, ntaps, transpose_flip, cpad, buf.data());
+  std::vector<char> buf(packed_weight_bytes(cdt, ntaps, cpad, Co));
+  pack_conv_weight(cdt, w_host, Cout, Cin, ntaps, transpose_flip, cpad, buf.data());
   void *wp = nullptr, *xin = nullptr, *ys = nullptr; float *bias = nullptr, *y32 = nullptr, *skws = nullptr;
   KDIP_HIP_CHECK(hipMalloc(&wp, buf.size()));
   KDIP_HIP_CHECK(hipMemcpy(wp, buf.data(), buf.size(), hipMemcpyHostToDevice));
@@ -345,11 +347,11 @@ int kdip_test_conv(void* stream, int dtype, int ntaps, const float* x_nchw, int 
     const long wsf = (long)B * H * W * Co;             // zeroed split-K workspace: under-filled shapes take the split-K path
     KDIP_HIP_CHECK(hipMalloc((void**)&skws, sizeof(float) * wsf));
     KDIP_HIP_CHECK(hipMemsetAsync(skws, 0, sizeof(float) * wsf, st));
-    if (!rc) rc = conv_forward(st, dt, ntaps, xin, cpad, B, H, W, cpad, wp, bias, Co, ys, opad, nullptr, 0, 0, 1.f, 0, nullptr, skws, wsf);
+    if (!rc) rc = conv_forward(st, cdt, ntaps, xin, cpad, B, H, W, cpad, wp, bias, Co, ys, opad, nullptr, 0, 0, 1.f, 0, nullptr, skws, wsf);
     if (!rc) rc = nhwc_T_to_nchw_f32(st, dt, ys, opad, B, Co, H, W, y_nchw);
   } else {               // the fp32-output epilogue of the output heads / final input gradient
     KDIP_HIP_CHECK(hipMalloc((void**)&y32, sizeof(float) * (size_t)B * H * W * opad));
-    if (!rc) rc = conv_forward(st, dt, ntaps, xin, cpad, B, H, W, cpad, wp, bias, Co, y32, opad, nullptr, 0, 1, 1.f);
+    if (!rc) rc = conv_forward(st, cdt, ntaps, xin, cpad, B, H, W, cpad, wp, bias, Co, y32, opad, nullptr, 0, 1, 1.f);
     if (!rc) rc = nhwc_to_nchw_f32(st, y32, opad, B, Co, H, W, y_nchw);
   }
   hipError_t e = hipStreamSynchronize(st);
@@ -360,14 +362,14 @@ int kdip_test_conv(void* stream, int dtype, int ntaps, const float* x_nchw, int 
 }
 
 // ------------------------------------------------------------------ stand-alone conv layers (LPIPS backbone) ----
-struct kdip_conv { DType dt; int cin, cout, cin_pad, ntaps, device; void* w = nullptr; float* bias = nullptr; };
+struct kdip_conv { DType dt, cdt; int cin, cout, cin_pad, ntaps, device; void* w = nullptr; float* bias = nullptr; };
 int kdip_conv_create(int device, int dtype, const float* w_host, const float* bias_host, int Cout, int Cin, int ntaps, kdip_conv** out) {
   KDIP_REQUIRE(out && w_host && (ntaps == 9 || ntaps == 1) && Cout > 0 && Cin > 0, "conv_create: bad arguments");
   KDIP_HIP_CHECK(hipSetDevice(device));
   kdip_conv* c = new kdip_conv;
-  c->dt = dtype == KDIP_BF16 ? DT_BF16 : DT_F32; c->cin = Cin; c->cout = Cout; c->cin_pad = pad32i(Cin); c->ntaps = ntaps; c->device = device;
-  std::vector<char> buf(packed_weight_bytes(c->dt, ntaps, c->cin_pad, Cout));
-  pack_conv_weight(c->dt, w_host, Cout, Cin, ntaps, 0, c->cin_pad, buf.data());
+  c->cdt = dtype == KDIP_BF16 ? DT_BF16 : (dtype == KDIP_BF16X3 ? DT_F32X3 : DT_F32); c->dt = storage_dtype(c->cdt); c->cin = Cin; c->cout = Cout; c->cin_pad = pad32i(Cin); c->ntaps = ntaps; c->device = device;
+  std::vector<char> buf(packed_weight_bytes(c->cdt, ntaps, c->cin_pad, Cout));
+  pack_conv_weight(c->cdt, w_host, Cout, Cin, ntaps, 0, c->cin_pad, buf.data());
   bool ok = hipMalloc(&c->w, buf.size()) == hipSuccess && hipMemcpy(c->w, buf.data(), buf.size(), hipMemcpyHostToDevice) == hipSuccess;
   if (ok && bias_host)
     ok = hipMalloc((void**)&c->bias, sizeof(float) * Cout) == hipSuccess &&
@@ -400,7 +402,7 @@ int kdip_conv_apply(kdip_conv* c, void* stream, const float* x_nchw, int B, int 
   float* y32 = (float*)(xin + ((es * (size_t)B * H * W * c->cin_pad + 255) & ~(size_t)255));
   const int opad = pad32i(c->cout);
   API_CK(nchw_to_nhwc(st, c->dt, x_nchw, B, c->cin, H, W, 1.f, xin, c->cin_pad, c->cin_pad));
-  API_CK(conv_forward(st, c->dt, c->ntaps, xin, c->cin_pad, B, H, W, c->cin_pad, c->w, c->bias, c->cout, y32, opad, nullptr, 0, 1, 1.f, c->cin));
+  API_CK(conv_forward(st, c->cdt, c->ntaps, xin, c->cin_pad, B, H, W, c->cin_pad, c->w, c->bias, c->cout, y32, opad, nullptr, 0, 1, 1.f, c->cin));
   return nhwc_to_nchw_f32(st, y32, opad, B, c->cout, H, W, y_nchw);
 }
 int kdip_gauss_nll_mean(void* stream, const float* pred, const float* target, const float* logvar, int B, long per, int accumulate, float* out) {

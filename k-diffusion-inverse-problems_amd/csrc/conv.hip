@@ -22,25 +22,40 @@
 // KDIP_TIMING=1 adds per-block phase stamps (tools/conv_phases.py).
 #include <atomic>
 #include <mutex>
+#include <type_traits>
 #include "common.h"
 #include "kernels.h"
 
 namespace kdip {
 
+// Operand fragments carry NP planes of 16 bytes per lane: one for bf16 / f32 storage, two (bf16 hi, bf16 lo) in the
+// split-precision mode; a k-step is issued as NTERM passes over the wave's (mt, nt) accumulators so that consecutive
+// MFMAs never chain on one accumulator.
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
   static constexpr int KSTEP = 16;  // channels per 16-byte-per-lane step
-  __device__ static inline void run(const uint4& a, const uint4& b, f32x16& c) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  static constexpr int NP = 1, NTERM = 1;
+  template <int TERM> __device__ static inline void run(const uint4 (&a)[1], const uint4 (&b)[1], f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, b[0]), c, 0, 0, 0);
   }
 };
 template <> struct Mma<float> {
   static constexpr int KSTEP = 8;
-  __device__ static inline void run(const uint4& a, const uint4& b, f32x16& c) {
+  static constexpr int NP = 1, NTERM = 4;
+  template <int TERM> __device__ static inline void run(const uint4 (&a)[1], const uint4 (&b)[1], f32x16& c) {
     // lane half h holds channels h*4+j; MFMA j contracts the pair {j, 4+j}
-    f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], bf[j], c, 0, 0, 0);
+    f32x4 af = __builtin_bit_cast(f32x4, a[0]), bf = __builtin_bit_cast(f32x4, b[0]);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[TERM], bf[TERM], c, 0, 0, 0);
+  }
+};
+// split precision (DT_F32X3): x = hi + lo, hi = bf16(x), lo = bf16(x - hi) (|x - hi - lo| <= 2^-18 |x|);
+// a*b ~ a_hi*b_hi + a_hi*b_lo + a_lo*b_hi (the dropped lo*lo term is ~2^-18 |a b|), fp32 accumulate.
+template <> struct Mma<f32x3_t> {
+  static constexpr int KSTEP = 16;
+  static constexpr int NP = 2, NTERM = 3;
+  template <int TERM> __device__ static inline void run(const uint4 (&a)[2], const uint4 (&b)[2], f32x16& c) {
+    constexpr int pa = TERM == 2 ? 1 : 0, pb = TERM == 1 ? 1 : 0;
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[pa]), __builtin_bit_cast(bf16x8, b[pb]), c, 0, 0, 0);
   }
 };
 
@@ -159,6 +174,12 @@ constexpr int KC = 32;            // input channels per B-pipeline stage (one ta
 #endif
 #ifndef KDIP_OCC
 #define KDIP_OCC 3
+#endif
+#ifndef KDIP_X3_OCC
+#define KDIP_X3_OCC 2        // split-precision instantiations: resident blocks per CU the register budget is set for
+#endif
+#ifndef KDIP_X3_B_DEPTH
+#define KDIP_X3_B_DEPTH 1    // ... and their weight-fragment stages in flight (two 16-byte planes per fragment)
 #endif
 
 
@@ -326,7 +347,9 @@ __device__ __forceinline__ void epilogue_bf16_fast(const ConvParams& p, f32x16 (
 // SUBS = 32-channel sub-chunks staged in LDS per barrier (1 for 3x3; up to 4 for 1x1 so a barrier
 // covers 32 MFMAs per wave instead of 8).
 template <typename T, int NTAPS, int WAVES_M, int WAVES_N, int MT, int NT, int SUBS>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 9) ? (MT * NT == 4 ? KDIP_OCC : (MT * NT == 8 ? 2 : 1)) : ((sizeof(T) == 2 && NTAPS == 1 && MT * NT == 4 && SUBS == 2) ? 3 : 1)) void conv_igemm_kernel(ConvParams p) {
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::value) ? KDIP_X3_OCC : (sizeof(T) == 2 && NTAPS == 9) ? (MT * NT == 4 ? KDIP_OCC : (MT * NT == 8 ? 2 : 1)) : ((sizeof(T) == 2 && NTAPS == 1 && MT * NT == 4 && SUBS == 2) ? 3 : 1)) void conv_igemm_kernel(ConvParams p) {
+  constexpr bool X3 = std::is_same<T, f32x3_t>::value;     // fp32 storage, operands split into bf16 hi / lo planes on the way into LDS
+  constexpr int NP = Mma<T>::NP, NTERM = Mma<T>::NTERM;
   constexpr int NTHREADS = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * MT * 32;
   constexpr int BN = WAVES_N * NT * 32;
@@ -446,14 +469,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
   const int nt0 = ntb * (BN / 32) + wn * NT;           // first n-tile of this wave
   const uint4* wp = (const uint4*)p.wp;
   const long kstepsTotal = (long)(p.Cin / KSTEP);
-  const long kStride = (long)p.ntilesN * 64;           // uint4 per k-step
+  const long kStride = (long)p.ntilesN * 64 * NP;      // uint4 per k-step ([n-tile][plane][lane])
   const long tapStride = kstepsTotal * kStride;        // uint4 per tap
   const uint4* wbase[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     int ntile = nt0 + nt;
     ntile = ntile < p.ntilesN ? ntile : p.ntilesN - 1;  // clamp (results discarded)
-    wbase[nt] = wp + (long)ntile * 64;
+    wbase[nt] = wp + (long)ntile * 64 * NP;
   }
   auto bptr = [&](int tap, long kstep, int nt) -> const uint4* {
     return wbase[nt] + (tap * tapStride + kstep * kStride) + lane;
@@ -492,7 +515,21 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
     for (int i = 0; i < MAXV; ++i)
     {
       const int v = tid + i * NTHREADS, pix = v / VPP;
-      if (pix < npix) *(uint4*)(smem + buf * abuf_bytes + pix * PIXB + (v % VPP) * 16) = areg[i];
+      if constexpr (X3) {
+        // 4 fp32 channels -> 4 bf16 hi (8 B) into the pixel's first KCH*2 bytes + 4 bf16 lo into the second KCH*2 bytes
+        if (pix < npix) {
+          float f[4];
+          unpack16<float>(areg[i], f);
+          const uint32_t h0 = pack_bf16x2(f[0], f[1]), h1 = pack_bf16x2(f[2], f[3]);
+          const uint32_t l0 = pack_bf16x2(f[0] - __uint_as_float(h0 << 16), f[1] - __uint_as_float(h0 & 0xffff0000u));
+          const uint32_t l1 = pack_bf16x2(f[2] - __uint_as_float(h1 << 16), f[3] - __uint_as_float(h1 & 0xffff0000u));
+          unsigned char* d = smem + buf * abuf_bytes + pix * PIXB + (v % VPP) * 8;
+          *(uint2*)d = make_uint2(h0, h1);
+          *(uint2*)(d + KCH * 2) = make_uint2(l0, l1);
+        }
+      } else {
+        if (pix < npix) *(uint4*)(smem + buf * abuf_bytes + pix * PIXB + (v % VPP) * 16) = areg[i];
+      }
     }
   };
 
@@ -500,16 +537,18 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
   // registers; a stage index past the end is clamped to the last stage (one redundant L2 hit) so the
   // loop body has no branches.
   const int nstages = nchunks_all * SUBS * NTAPS;
-  auto load_b = [&](uint4 (&dst)[KS][NT], int stage) {
+  auto load_b = [&](uint4 (&dst)[KS][NT][NP], int stage) {
     stage = stage < nstages ? stage : nstages - 1;
     const int c32 = stage / NTAPS, tp = stage - c32 * NTAPS;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) dst[ks][nt] = *bptr(tp, (long)c32 * KS + ks, nt);
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) dst[ks][nt][pl] = bptr(tp, (long)c32 * KS + ks, nt)[pl * 64];
   };
-  constexpr int BD = (MT * NT <= 2 && sizeof(T) == 2 && NTAPS == 9) ? KDIP_B_DEPTH_SMALL : KDIP_B_DEPTH;   // stages ahead
-  uint4 bq[BD + 1][KS][NT];
+  constexpr int BD = X3 ? KDIP_X3_B_DEPTH : (MT * NT <= 2 && sizeof(T) == 2 && NTAPS == 9) ? KDIP_B_DEPTH_SMALL : KDIP_B_DEPTH;   // stages ahead
+  uint4 bq[BD + 1][KS][NT][NP];
 
   // prologue: the first two B stages are requested together with the first patch, ahead of the LDS write + barrier
   // (issued after the barrier their L2 latency sat exposed in front of the first MFMA)
@@ -524,14 +563,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
 
   // A fragments of the next (sub, tap) stage are read from LDS one stage ahead, so the ds_reads
   // of stage s+1 are in flight under the MFMAs of stage s.
-  auto load_a = [&](uint4 (&dst)[KS][MT], const unsigned char* abuf, int sub, int tap) {
-    const int toff = ((NTAPS == 9) ? ((tap / 3) * HW_ + (tap % 3)) * PIXB : 0) + sub * KC * (int)sizeof(T);
+  auto load_a = [&](uint4 (&dst)[KS][MT][NP], const unsigned char* abuf, int sub, int tap) {
+    const int toff = ((NTAPS == 9) ? ((tap / 3) * HW_ + (tap % 3)) * PIXB : 0) + sub * KC * (X3 ? 2 : (int)sizeof(T));
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) dst[ks][mt] = *(const uint4*)(abuf + abase[mt] + toff + ks * 32);
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) dst[ks][mt][pl] = *(const uint4*)(abuf + abase[mt] + toff + ks * 32 + pl * (KCH * 2));
   };
-  uint4 aq0[KS][MT], aq1[KS][MT];
+  uint4 aq0[KS][MT][NP], aq1[KS][MT][NP];
   // what the staging slots of chunk c fetch: the next chunk of this tile, or (last chunk of a prefetching tile) chunk 0 of
   // the block's next tile -- from then on goff describes that tile
   auto next_load = [&](int c) {
@@ -565,11 +606,28 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
         }
         if (KDIP_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
+        for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) Mma<T>::run(aq0[ks][mt], bq[0][ks][nt], acc[mt][nt]);
+            for (int nt = 0; nt < NT; ++nt) Mma<T>::template run<0>(aq0[ks][mt], bq[0][ks][nt], acc[mt][nt]);
+          if constexpr (NTERM > 1) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) Mma<T>::template run<1>(aq0[ks][mt], bq[0][ks][nt], acc[mt][nt]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) Mma<T>::template run<2>(aq0[ks][mt], bq[0][ks][nt], acc[mt][nt]);
+          }
+          if constexpr (NTERM > 3) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) Mma<T>::template run<3>(aq0[ks][mt], bq[0][ks][nt], acc[mt][nt]);
+          }
+        }
         if (KDIP_SETPRIO) __builtin_amdgcn_s_setprio(0);
         if (!KDIP_ABL_NOSTAGE && NTAPS * SUBS > 1 && sub == 0 && tap == 0) next_load(c);
         // the other LDS buffer was last read in chunk c-1 (all waves are past that barrier), so the next
@@ -580,11 +638,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (sizeof(T) == 2 && NTAPS == 
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
-            for (int i = 0; i < BD; ++i) bq[i][ks][nt] = bq[i + 1][ks][nt];
+            for (int i = 0; i < BD; ++i)
+#pragma unroll
+              for (int pl = 0; pl < NP; ++pl) bq[i][ks][nt][pl] = bq[i + 1][ks][nt][pl];
           }
           if (KDIP_A_PREFETCH) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) aq0[ks][mt] = aq1[ks][mt];
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int pl = 0; pl < NP; ++pl) aq0[ks][mt][pl] = aq1[ks][mt][pl];
           }
         }
         if (!KDIP_A_PREFETCH) {
@@ -932,8 +994,9 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
   if (splits > 1) {
     const long npix = (long)p.B * p.H * p.W;
     long g = (npix * (p.Cout / 4) + 255) / 256; if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(conv_splitk_finalize_kernel<T>, dim3((unsigned)g), dim3(256), 0, st, p.sk_ws, p.bias, (const T*)p.res, p.ldr, npix, p.Cout,
-                       (T*)p.y, p.ldy);
+    using ST = std::conditional_t<std::is_same<T, f32x3_t>::value, float, T>;      // storage type
+    hipLaunchKernelGGL(conv_splitk_finalize_kernel<ST>, dim3((unsigned)g), dim3(256), 0, st, p.sk_ws, p.bias, (const ST*)p.res, p.ldr, npix, p.Cout,
+                       (ST*)p.y, p.ldy);
   }
   prof_end(st);
   KDIP_LAUNCH_CHECK();
@@ -949,6 +1012,8 @@ static int launch_cfg(ConvParams& p, hipStream_t st) {
     if (sizeof(T) == 2 && MT * NT == 4 && p.Cin % 64 == 0) return launch_cfg2<T, NTAPS, WAVES_M, WAVES_N, MT, NT, (NTAPS == 1 ? 2 : 1)>(p, st);
     if (KDIP_SUBS1 >= 4 && sizeof(T) == 2 && p.Cin % 128 == 0) return launch_cfg2<T, NTAPS, WAVES_M, WAVES_N, MT, NT, (NTAPS == 1 ? 4 : 1)>(p, st);
     if (KDIP_SUBS1 >= 2 && sizeof(T) == 2 && p.Cin % 64 == 0) return launch_cfg2<T, NTAPS, WAVES_M, WAVES_N, MT, NT, (NTAPS == 1 ? 2 : 1)>(p, st);
+    // split precision: 64 channels (12 MFMAs per accumulator) per barrier
+    if (std::is_same<T, f32x3_t>::value && p.Cin % 64 == 0) return launch_cfg2<T, NTAPS, WAVES_M, WAVES_N, MT, NT, (NTAPS == 1 ? 2 : 1)>(p, st);
   }
 #if KDIP_SUBS3 > 1
   if (NTAPS == 9 && sizeof(T) == 2 && MT * NT == 4 && p.Cin % (32 * KDIP_SUBS3) == 0)
@@ -1000,6 +1065,7 @@ int conv_forward(hipStream_t st, DType dt, int ntaps, const void* x, long ldx, i
     p.st_coef = stt->coef; p.st_mr = stt->mr;
   }
   if (dt == DT_BF16) return ntaps == 9 ? launch_T<bf16_t, 9>(p, st) : launch_T<bf16_t, 1>(p, st);
+  if (dt == DT_F32X3) return ntaps == 9 ? launch_T<f32x3_t, 9>(p, st) : launch_T<f32x3_t, 1>(p, st);
   return ntaps == 9 ? launch_T<float, 9>(p, st) : launch_T<float, 1>(p, st);
 }
 
@@ -1008,6 +1074,7 @@ int conv_forward(hipStream_t st, DType dt, int ntaps, const void* x, long ldx, i
 // transpose_flip: build the dgrad weight W'[ci][co][ky][kx] = W[co][ci][kh-1-ky][kw-1-kx].
 // Output element (tap, kstep, ntile, lane, e) = W[n][k][tap], n = ntile*32 + (lane&31),
 // k = kstep*KSTEP + (lane>>5)*EPL + e; zero outside [Cout) x [Cin).
+// DT_F32X3: (tap, kstep, ntile, plane, lane, e) with plane 0 = bf16(W), plane 1 = bf16(W - plane 0), bf16 k-steps.
 size_t packed_weight_bytes(DType dt, int ntaps, int Cin_pad, int Cout) {
   size_t es = dt == DT_BF16 ? 2 : 4;
   return (size_t)ntaps * Cin_pad * cdiv(Cout, 32) * 32 * es;
@@ -1017,13 +1084,28 @@ void pack_conv_weight(DType dt, const float* w, int Cout, int Cin, int ntaps, in
                       void* out) {
   // logical conv after optional transpose: Co x Ci
   const int Co = transpose_flip ? Cin : Cout, Ci = transpose_flip ? Cout : Cin;
-  const int kstep = dt == DT_BF16 ? 16 : 8, epl = dt == DT_BF16 ? 8 : 4;
+  const int kstep = dt == DT_F32 ? 8 : 16, epl = dt == DT_F32 ? 4 : 8;
   const int ksteps = Cin_pad_out / kstep, ntiles = cdiv(Co, 32);
   auto W = [&](int n, int k, int tap) -> float {
     if (n >= Co || k >= Ci) return 0.f;
     if (!transpose_flip) return w[((long)n * Cin + k) * ntaps + tap];
     return w[((long)k * Cin + n) * ntaps + (ntaps - 1 - tap)];
   };
+  if (dt == DT_F32X3) {
+    bf16_t* o = (bf16_t*)out;
+    long idx = 0;
+    for (int tap = 0; tap < ntaps; ++tap)
+      for (int ks = 0; ks < ksteps; ++ks)
+        for (int nt = 0; nt < ntiles; ++nt, idx += 2 * 64 * 8)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int e = 0; e < 8; ++e) {
+              const float v = W(nt * 32 + (lane & 31), ks * 16 + (lane >> 5) * 8 + e, tap);
+              const bf16_t hi = f32_to_bf16(v);
+              o[idx + lane * 8 + e] = hi;
+              o[idx + 64 * 8 + lane * 8 + e] = f32_to_bf16(v - bf16_to_f32(hi));
+            }
+    return;
+  }
   long idx = 0;
   for (int tap = 0; tap < ntaps; ++tap)
     for (int ks = 0; ks < ksteps; ++ks)

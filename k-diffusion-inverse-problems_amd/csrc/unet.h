@@ -57,7 +57,8 @@ struct Arena {
 
 struct UNet {
   UNetConfig cfg;
-  DType dt;
+  DType dt;                         // activation storage type (DT_F32 | DT_BF16)
+  DType cdt;                        // conv arithmetic / packed-weight type: dt, or DT_F32X3 (fp32 storage, split-bf16 MFMA) when dt == DT_F32
   int device = 0;
   std::vector<std::vector<Layer>> inp, out;
   std::vector<Layer> mid;

@@ -190,11 +190,11 @@ int UNet::finalize() {
     const float* b = need(p + ".bias", cout);
     if (!w || !b) return;
     c.cin = cin; c.cout = cout; c.ntaps = ntaps; c.cin_pad = pad32(cin); c.cin_pad_b = pad32(cout);
-    std::vector<char> buf(packed_weight_bytes(dt, ntaps, c.cin_pad, cout));
-    pack_conv_weight(dt, w, cout, cin, ntaps, 0, c.cin_pad, buf.data());
+    std::vector<char> buf(packed_weight_bytes(cdt, ntaps, c.cin_pad, cout));
+    pack_conv_weight(cdt, w, cout, cin, ntaps, 0, c.cin_pad, buf.data());
     c.wf = upload(buf.data(), buf.size());
-    std::vector<char> bufb(packed_weight_bytes(dt, ntaps, c.cin_pad_b, cin));
-    pack_conv_weight(dt, w, cout, cin, ntaps, 1, c.cin_pad_b, bufb.data());
+    std::vector<char> bufb(packed_weight_bytes(cdt, ntaps, c.cin_pad_b, cin));
+    pack_conv_weight(cdt, w, cout, cin, ntaps, 1, c.cin_pad_b, bufb.data());
     c.wb = upload(bufb.data(), bufb.size());
     c.bias = (float*)upload(b, sizeof(float) * cout);
   };
@@ -270,6 +270,7 @@ void unet_debug_gn_fold(int on) { g_gn_fold.store(on ? 1 : 0); }
 namespace {
 struct Ctx {
   UNet* u; hipStream_t st; bool dry; DType dt; size_t es;
+  DType cdt() const { return u->cdt; }
 };
 
 double* new_sums(Ctx& c, int B) { return (double*)c.u->zeros.alloc(sizeof(double) * B * 64); }
@@ -398,7 +399,7 @@ int conv_f(Ctx& c, const ConvW& w, const void* x, long ldx, int B, int H, int W,
     stt.sums = new_sums(c, B);
     c.u->fused_stats[std::make_pair((const void*)y, w.cout)] = stt.sums;
   }
-  RUN(conv_forward(c.st, c.dt, w.ntaps, x, ldx, B, H, W, w.cin_pad, w.wf, w.bias, w.cout, y, ldy, res, ldr, out_f32, 1.f, w.cin,
+  RUN(conv_forward(c.st, c.cdt(), w.ntaps, x, ldx, B, H, W, w.cin_pad, w.wf, w.bias, w.cout, y, ldy, res, ldr, out_f32, 1.f, w.cin,
                    (stt.mode || in_ups || res_ups) ? &stt : nullptr, c.u->sk_ws, c.u->sk_ws_floats));
   return KDIP_OK;
 }
@@ -437,7 +438,7 @@ int conv_b(Ctx& c, const ConvW& w, const void* g, long ldg, int B, int H, int W,
     stt.sums = new_sums(c, B);
     *sums_out = stt.sums;
   }
-  RUN(conv_forward(c.st, c.dt, w.ntaps, g, ldg, B, H, W, w.cin_pad_b, w.wb, nullptr, w.cin, y, ldy, res, ldr, out_f32, 1.f, w.cout,
+  RUN(conv_forward(c.st, c.cdt(), w.ntaps, g, ldg, B, H, W, w.cin_pad_b, w.wb, nullptr, w.cin, y, ldy, res, ldr, out_f32, 1.f, w.cout,
                    stt.mode ? &stt : nullptr, c.u->sk_ws, c.u->sk_ws_floats));
   return KDIP_OK;
 }

@@ -66,7 +66,7 @@ class LPIPS:
             if tuple(w.shape) != (cout, cin, 3, 3):
                 raise ValueError(f"LPIPS: features[{idx}].weight has shape {tuple(w.shape)}, expected {(cout, cin, 3, 3)}")
             h = C.c_void_p()
-            L.check(self.lib.kdip_conv_create(self.device.index, L.BF16 if self.dtype == "bf16" else L.F32, C.c_void_p(w.data_ptr()),
+            L.check(self.lib.kdip_conv_create(self.device.index, L.DTYPES[self.dtype], C.c_void_p(w.data_ptr()),
                                               C.c_void_p(b.data_ptr()), cout, cin, 9, C.byref(h)))
             self._convs.append(h)
         self._lin = []

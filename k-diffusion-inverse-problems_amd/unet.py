@@ -77,7 +77,9 @@ class UNetModel:
         h = C.c_void_p()
         ads = (C.c_int * len(self.attention_ds))(*self.attention_ds)
         cms = (C.c_int * len(self.channel_mult))(*self.channel_mult)
-        L.check(self.lib.kdip_unet_create(dev.index, L.BF16 if dtype == "bf16" else L.F32, image_size, in_channels,
+        if dtype not in L.DTYPES:
+            raise ValueError(f"dtype must be one of {sorted(L.DTYPES)} (got {dtype!r})")
+        L.check(self.lib.kdip_unet_create(dev.index, L.DTYPES[dtype], image_size, in_channels,
                                           model_channels, out_channels, num_res_blocks, ads, len(self.attention_ds),
                                           cms, len(self.channel_mult), num_head_channels, C.byref(h)))
         self._h = h

@@ -30,7 +30,7 @@ def tiny():
     cfg = ounet.UNetConfig(**ounet.TINY)
     sd = ounet.init_state_dict(cfg, seed=0, out_cov=True)
     models = {}
-    for dt in ("f32", "bf16"):
+    for dt in ("f32", "bf16", "bf16x3"):
         m = ku.UNetModel(image_size=64, model_channels=32, num_res_blocks=1, attention_resolutions="32",
                          channel_mult=(1, 2), dtype=dt)
         m.load_state_dict(sd)
@@ -188,27 +188,27 @@ def test_guided_calls_golden(gold, tiny, name):
     g = gold("guided_calls")
     hop, oop, (y, yf), x0 = make_ops(name, gold)
     meas = (y.cuda(), yf.cuda())
-    worst = {"f32": 0.0}
+    worst = {"f32": 0.0, "bf16x3": 0.0}
     min_psnr = 1e9
     for guidance, cov, extra in GUIDED:
         for sigma_v in (1.5, 0.12):
             x = (x0 + sigma_v * torch.randn(1, 3, 64, 64, generator=torch.Generator().manual_seed(11))).cuda()
             ref = T(g[f"{name}|{guidance}|{cov}|{sigma_v}"])
-            for dt in ("f32", "bf16"):
+            for dt in ("f32", "bf16x3", "bf16"):
                 m = kc.ConditionOpenAIDenoiser(inner_model=models[dt], diffusion=D, x0_cov_type=cov,
                                                recon_mse=synthetic_recon_mse(), operator=hop, measurement=meas,
                                                guidance=guidance, zeta=extra.get("zeta"), lambda_=extra.get("lambda_"),
                                                mle_sigma_thres=0.2, device="cuda").eval()
                 hat = m(x, torch.tensor([sigma_v], device="cuda")).cpu()
-                if dt == "f32":
+                if dt != "bf16":       # exact-f32 MFMA and split-precision (bf16x3) convs: the same bound
                     err = float((hat - ref).abs().max())
-                    worst["f32"] = max(worst["f32"], err)
-                    assert err < 2e-3, (name, guidance, cov, sigma_v, err)
+                    worst[dt] = max(worst[dt], err)
+                    assert err < 2e-3, (dt, name, guidance, cov, sigma_v, err)
                 else:
                     p = psnr_db(hat, ref)
                     min_psnr = min(min_psnr, p)
                     assert p > 30.0, (name, guidance, cov, sigma_v, p)
-    print(f"\n[{name}] f32 worst max-abs {worst['f32']:.2e}; bf16 min PSNR vs reference {min_psnr:.1f} dB")
+    print(f"\n[{name}] f32 worst max-abs {worst['f32']:.2e}; bf16x3 worst max-abs {worst['bf16x3']:.2e}; bf16 min PSNR vs reference {min_psnr:.1f} dB")
 
 
 def test_guided_calls_v2_golden(gold, tiny):
@@ -346,8 +346,31 @@ def test_error_behaviour(gold, tiny):
 
 
 # --------------------------------------------------------------------------- sampler ----
-def test_sampler_golden(gold, tiny):
+# Sampler-run bounds per arithmetic mode: (max-abs of the final image, |PSNR_hip - PSNR_ref| in dB against the ground truth).
+#   f32     exact-f32 MFMA: the north_star tolerance (1e-3 dB) and a max-abs bound.
+#   bf16x3  split-precision convs (per-conv error 5e-6 vs 1e-6, per guided call 3e-5 vs 3e-6 max-abs): held to the same 1e-3 dB.  No
+#           max-abs bound: the tiny random-weight model saturates its output at +-1 and the 4-step trajectory is chaotic, so the
+#           8 x larger per-call round-off can move single pixels by O(1) (one pixel of 64 x 64 x 3 flipping -1 -> +1 = 1.2e-3 dB);
+#           the number of such pixels is printed and bounded.
+#   bf16    production throughput mode: 3 x the measured deviation (0.004 / 0.014 dB).
+SAMPLER_BOUNDS = {"f32": (5e-3, 1e-3), "bf16x3": (None, 1e-3), "bf16": (None, 0.05)}
+
+
+def _sampler_case(models, D, hop, meas, x0, dt, fn, xT, sig, ref, **kw):
     import kdip_amd.condition as kc
+    from kdip_amd.evaluation import psnr
+    m = kc.ConditionOpenAIDenoiser(inner_model=models[dt], diffusion=D, x0_cov_type="convert", recon_mse=None,
+                                   operator=hop, measurement=meas, guidance="I", device="cuda").eval()
+    seen = []
+    x = fn(m, xT.cuda(), sig, disable=True, callback=lambda d: seen.append(d["i"]), **kw).cpu()
+    assert seen == [0, 1, 2, 3]
+    err = float((x - ref).abs().max())
+    dp = abs(float(psnr(x, x0)) - float(psnr(ref, x0)))
+    moved = int(((x - ref).abs() > 1e-2).sum())
+    return err, dp, moved
+
+
+def test_sampler_golden(gold, tiny):
     import kdip_amd.sampling as ks
     models, D, sd, cfg = tiny
     g = gold("sampler")
@@ -356,56 +379,42 @@ def test_sampler_golden(gold, tiny):
     sig = ks.get_sigmas_karras(4, 0.01, 80, rho=7.0, device="cuda")
     assert torch.equal(sig.cpu(), T(g["sigmas"]))
     assert torch.equal(ks.get_sigmas_karras(100, 0.01, 80).cpu(), T(gold("tables")["sigmas100"]))
+    bad = []
     for sampler, fn in (("heun", ks.sample_heun), ("euler", ks.sample_euler)):
-        m = kc.ConditionOpenAIDenoiser(inner_model=models["f32"], diffusion=D, x0_cov_type="convert", recon_mse=None,
-                                       operator=hop, measurement=meas, guidance="I", device="cuda").eval()
-        seen = []
-        x = fn(m, T(g["xT"]).cuda(), sig, disable=True, callback=lambda d: seen.append(d["i"]))
-        assert seen == [0, 1, 2, 3]
-        ref = T(g[f"{sampler}.x0"])
-        err = float((x.cpu() - ref).abs().max())
-        assert err < 5e-3, (sampler, err)
-        # PSNR contract of north_star: |PSNR_hip - PSNR_ref| against the ground truth <= 1e-3 dB (f32 mode)
-        from kdip_amd.evaluation import psnr
-        dp = abs(float(psnr(x.cpu(), x0)) - float(psnr(ref, x0)))
-        assert dp < 1e-3, (sampler, dp)
-        # the production (bf16) arithmetic on the same reference trajectory: reported, and bounded at what it holds
-        mb = kc.ConditionOpenAIDenoiser(inner_model=models["bf16"], diffusion=D, x0_cov_type="convert", recon_mse=None,
-                                        operator=hop, measurement=meas, guidance="I", device="cuda").eval()
-        xb = fn(mb, T(g["xT"]).cuda(), sig, disable=True)
-        dpb = abs(float(psnr(xb.cpu(), x0)) - float(psnr(ref, x0)))
-        print(f"\n{sampler} 4-step ode, tiny model: f32 max-abs {err:.2e} dPSNR {dp:.1e} dB; bf16 max-abs "
-              f"{float((xb.cpu() - ref).abs().max()):.2e} dPSNR {dpb:.1e} dB vs the reference capture")
-        assert dpb < 0.25, (sampler, dpb)
+        for dt, (emax, dpmax) in SAMPLER_BOUNDS.items():
+            err, dp, moved = _sampler_case(models, D, hop, meas, x0, dt, fn, T(g["xT"]), sig, T(g[f"{sampler}.x0"]))
+            print(f"\n{sampler} 4-step ode, tiny model, {dt}: max-abs {err:.2e}, dPSNR {dp:.1e} dB, {moved} of 12288 values moved > 1e-2 vs the reference capture")
+            if (emax is not None and err >= emax) or dp >= dpmax or (dt == "bf16x3" and moved > 8):
+                bad.append((sampler, dt, err, dp, moved))
+    assert not bad, bad
 
 
 def test_sampler_churn_golden(gold, tiny):
     """Stochastic samplers (s_churn > 0, k_diffusion/sampling.py:123-127,164-169) against the reference's churn
     trajectories: the per-step noise is drawn on the CPU generator exactly as the reference capture drew it
     (torch.manual_seed(7), one randn_like per step) and injected through `noise_fn`, so kdip_sampler_add_noise is
-    compared value-for-value (f32 mode)."""
-    import kdip_amd.condition as kc
+    compared value-for-value."""
     import kdip_amd.sampling as ks
-    from kdip_amd.evaluation import psnr
     models, D, sd, cfg = tiny
     g = gold("sampler")
     hop, oop, (y, yf), x0 = make_ops("gaussian_blur", gold)
     meas = (y.cuda(), yf.cuda())
     sig = ks.get_sigmas_karras(4, 0.01, 80, rho=7.0, device="cuda")
+    bad = []
     for sampler, fn in (("heun", ks.sample_heun), ("euler", ks.sample_euler)):
-        m = kc.ConditionOpenAIDenoiser(inner_model=models["f32"], diffusion=D, x0_cov_type="convert", recon_mse=None,
-                                       operator=hop, measurement=meas, guidance="I", device="cuda").eval()
-        torch.manual_seed(7)
-        cpu_noise = lambda x: torch.randn(x.shape)           # the reference's global CPU stream
-        x = fn(m, T(g["xT"]).cuda(), sig, disable=True, s_churn=80, s_tmin=0.05, s_tmax=50, s_noise=1.003, noise_fn=cpu_noise)
         ref = T(g[f"{sampler}.x0_churn"])
-        err = float((x.cpu() - ref).abs().max())
-        dp = abs(float(psnr(x.cpu(), x0)) - float(psnr(ref, x0)))
-        print(f"\nchurn {sampler}: max-abs {err:.2e}, dPSNR {dp:.2e} dB")
-        assert err < 5e-3, (sampler, err)
-        assert dp < 1e-3, (sampler, dp)
         # the churned trajectory must differ from the ode one (the noise really went in)
         assert float((ref - T(g[f"{sampler}.x0"])).abs().max()) > 1e-3
+        for dt in ("f32", "bf16x3"):
+            emax, dpmax = SAMPLER_BOUNDS[dt]
+            torch.manual_seed(7)
+            cpu_noise = lambda x: torch.randn(x.shape)           # the reference's global CPU stream
+            err, dp, moved = _sampler_case(models, D, hop, meas, x0, dt, fn, T(g["xT"]), sig, ref, s_churn=80, s_tmin=0.05, s_tmax=50,
+                                           s_noise=1.003, noise_fn=cpu_noise)
+            print(f"\nchurn {sampler} {dt}: max-abs {err:.2e}, dPSNR {dp:.2e} dB, {moved} of 12288 values moved > 1e-2")
+            if (emax is not None and err >= emax) or dp >= dpmax or (dt == "bf16x3" and moved > 8):
+                bad.append((sampler, dt, err, dp, moved))
+    assert not bad, bad
 
 
 def test_sampler_dpmpp2m_golden(gold, tiny):

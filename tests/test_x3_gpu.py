@@ -1,0 +1,58 @@
+"""GPU: the split-precision conv arithmetic (KDIP_BF16X3: fp32 storage, operands split into bf16 hi + bf16 lo, hi*hi + hi*lo + lo*hi
+on v_mfma_f32_32x32x16_bf16 with fp32 accumulation) against an fp64 reference of the same conv, next to the exact-f32 and plain
+bf16 kernels on the same data: the error ladder the mode is built on (reference arithmetic: fp32 end to end,
+condition/diffpir_utils/utils_model.py:364 use_fp16=False, guided_diffusion/unet.py:182-213)."""
+import ctypes as C
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _conv(L, dtype, x, w, b, ntaps, transpose_flip=0, storage_out=1):
+    B, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    n_out = w.shape[1] if transpose_flip else Cout
+    n_in = Cout if transpose_flip else Cin
+    y = torch.empty(B, n_out, H, W, device="cuda")
+    xd = x.cuda()
+    assert xd.shape[1] == n_in
+    L.check(L.load().kdip_test_conv(L.stream(), dtype, ntaps, L.ptr(xd), B, w.shape[1], H, W, C.c_void_p(w.contiguous().data_ptr()),
+                                    C.c_void_p(b.data_ptr()) if b is not None else None, Cout, transpose_flip, L.ptr(y), storage_out))
+    return y.cpu()
+
+
+@pytest.mark.parametrize("case", [(2, 128, 128, 64, 64, 9), (1, 256, 128, 32, 32, 9), (4, 512, 512, 8, 8, 9), (2, 256, 768, 16, 16, 1), (1, 128, 6, 64, 64, 9)])
+def test_x3_error_ladder_vs_fp64(case):
+    import kdip_amd._lib as L
+    L.require_gpu()
+    B, Cin, Cout, H, W, ntaps = case
+    k = 3 if ntaps == 9 else 1
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, Cin, H, W, generator=g) * torch.exp(torch.randn(B, Cin, 1, 1, generator=g))      # per-channel scales over ~2 decades
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * ntaps) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=k // 2)
+    scale = float(ref.abs().max())
+    err = {name: float((_conv(L, code, x, w, b, ntaps).double() - ref).abs().max()) / scale for name, code in (("f32", 0), ("bf16", 1), ("bf16x3", 2))}
+    print(f"\nconv {case}: max|err|/max|ref| f32 {err['f32']:.2e}  bf16x3 {err['bf16x3']:.2e}  bf16 {err['bf16']:.2e}")
+    assert err["f32"] < 2e-6
+    assert err["bf16x3"] < 8e-6                      # measured 1e-6 .. 3e-6: within a small factor of exact f32
+    assert err["bf16x3"] < err["bf16"] / 200         # and >= 200 x below the plain bf16 kernel on the same data
+
+
+def test_x3_dgrad_and_fp32_head():
+    """the dgrad packing (flipped + transposed hi / lo planes) and the fp32-output head epilogue of the split-precision kernel"""
+    import kdip_amd._lib as L
+    L.require_gpu()
+    g = torch.Generator().manual_seed(6)
+    B, Cin, Cout, H, W = 2, 96, 160, 32, 32
+    x = torch.randn(B, Cin, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    go = torch.randn(B, Cout, H, W, generator=g)
+    ref = torch.autograd.grad((F.conv2d(x, w.double(), None, padding=1) * go.double()).sum(), x)[0]
+    for so in (0, 1):
+        y = _conv(L, 2, go, w, None, 9, transpose_flip=1, storage_out=so)
+        e = float((y.double() - ref).abs().max() / ref.abs().max())
+        assert e < 8e-6, (so, e)
