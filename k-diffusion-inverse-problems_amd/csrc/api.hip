@@ -342,19 +342,29 @@ int kdip_test_conv(void* stream, int dtype, int ntaps, const float* x_nchw, int 
   KDIP_HIP_CHECK(hipMalloc(&xin, es * (size_t)B * H * W * cpad));
   const int opad = pad32i(Co);
   int rc = nchw_to_nhwc(st, dt, x_nchw, B, Ci, H, W, 1.f, xin, cpad, cpad);
+  // split-precision mode: a dgrad input is a gradient (no natural scale), so -- as the UNet's VJP does -- the fp16 window of the A
+  // operand follows max |x|; forward inputs are taken at O(1) scale
+  ConvStats stt;
+  unsigned* amax = nullptr;
+  if (cdt == DT_F32X3 && transpose_flip) {
+    KDIP_HIP_CHECK(hipMalloc((void**)&amax, sizeof(unsigned)));
+    if (!rc) rc = amax_bits(st, x_nchw, (long)B * Ci * H * W, amax);
+    stt.x3_amax = amax;
+  }
   if (storage_out) {     // the UNet-internal epilogues: output in the storage dtype
     KDIP_HIP_CHECK(hipMalloc(&ys, es * (size_t)B * H * W * opad));
     const long wsf = (long)B * H * W * Co;             // zeroed split-K workspace: under-filled shapes take the split-K path
     KDIP_HIP_CHECK(hipMalloc((void**)&skws, sizeof(float) * wsf));
     KDIP_HIP_CHECK(hipMemsetAsync(skws, 0, sizeof(float) * wsf, st));
-    if (!rc) rc = conv_forward(st, cdt, ntaps, xin, cpad, B, H, W, cpad, wp, bias, Co, ys, opad, nullptr, 0, 0, 1.f, 0, nullptr, skws, wsf);
+    if (!rc) rc = conv_forward(st, cdt, ntaps, xin, cpad, B, H, W, cpad, wp, bias, Co, ys, opad, nullptr, 0, 0, 1.f, 0, amax ? &stt : nullptr, skws, wsf);
     if (!rc) rc = nhwc_T_to_nchw_f32(st, dt, ys, opad, B, Co, H, W, y_nchw);
   } else {               // the fp32-output epilogue of the output heads / final input gradient
     KDIP_HIP_CHECK(hipMalloc((void**)&y32, sizeof(float) * (size_t)B * H * W * opad));
-    if (!rc) rc = conv_forward(st, cdt, ntaps, xin, cpad, B, H, W, cpad, wp, bias, Co, y32, opad, nullptr, 0, 1, 1.f);
+    if (!rc) rc = conv_forward(st, cdt, ntaps, xin, cpad, B, H, W, cpad, wp, bias, Co, y32, opad, nullptr, 0, 1, 1.f, 0, amax ? &stt : nullptr);
     if (!rc) rc = nhwc_to_nchw_f32(st, y32, opad, B, Co, H, W, y_nchw);
   }
   hipError_t e = hipStreamSynchronize(st);
+  if (amax) (void)hipFree(amax);
   (void)hipFree(wp); (void)hipFree(xin); if (y32) (void)hipFree(y32); if (ys) (void)hipFree(ys); if (skws) (void)hipFree(skws); if (bias) (void)hipFree(bias);
   if (rc) return rc;
   KDIP_HIP_CHECK(e);

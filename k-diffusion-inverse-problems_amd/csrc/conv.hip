@@ -23,39 +23,88 @@
 #include <atomic>
 #include <mutex>
 #include <type_traits>
+#include <math.h>
 #include "common.h"
 #include "kernels.h"
 
 namespace kdip {
 
-// Operand fragments carry NP planes of 16 bytes per lane: one for bf16 / f32 storage, two (bf16 hi, bf16 lo) in the
-// split-precision mode; a k-step is issued as NTERM passes over the wave's (mt, nt) accumulators so that consecutive
-// MFMAs never chain on one accumulator.
+// Operand fragments carry NPA / NPB planes of 16 bytes per lane (one for bf16 / f32 storage, several in the split-precision
+// mode); a k-step is issued as NTERM passes over the wave's (mt, nt) accumulators so that consecutive MFMAs never chain on
+// one accumulator.
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
   static constexpr int KSTEP = 16;  // channels per 16-byte-per-lane step
-  static constexpr int NP = 1, NTERM = 1;
-  template <int TERM> __device__ static inline void run(const uint4 (&a)[1], const uint4 (&b)[1], f32x16& c) {
+  static constexpr int NPA = 1, NPB = 1, NTERM = 1, LDS_BPC = 2;      // LDS_BPC: staged bytes per channel
+  template <int TERM> __device__ static inline void run(const uint4 (&a)[1], const uint4 (&b)[1], const uint4&, f32x16& c) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, b[0]), c, 0, 0, 0);
   }
 };
 template <> struct Mma<float> {
   static constexpr int KSTEP = 8;
-  static constexpr int NP = 1, NTERM = 4;
-  template <int TERM> __device__ static inline void run(const uint4 (&a)[1], const uint4 (&b)[1], f32x16& c) {
+  static constexpr int NPA = 1, NPB = 1, NTERM = 4, LDS_BPC = 4;
+  template <int TERM> __device__ static inline void run(const uint4 (&a)[1], const uint4 (&b)[1], const uint4&, f32x16& c) {
     // lane half h holds channels h*4+j; MFMA j contracts the pair {j, 4+j}
     f32x4 af = __builtin_bit_cast(f32x4, a[0]), bf = __builtin_bit_cast(f32x4, b[0]);
     c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[TERM], bf[TERM], c, 0, 0, 0);
   }
 };
-// split precision (DT_F32X3): x = hi + lo, hi = bf16(x), lo = bf16(x - hi) (|x - hi - lo| <= 2^-18 |x|);
-// a*b ~ a_hi*b_hi + a_hi*b_lo + a_lo*b_hi (the dropped lo*lo term is ~2^-18 |a b|), fp32 accumulate.
+// Split precision (DT_F32X3), three 16-bit MFMAs per product instead of one fp32 product, ONE fp32 accumulator.
+//
+// KDIP_X3_MIXED 1 (default): bf16 head + fp16 tails.  With a_hi = bf16(a), a_lo = a - a_hi (exact), likewise b:
+//     a*b = a_hi*b_hi  +  a*b_lo  +  a_lo*b_hi                                  (exact identity)
+//   acc += bf16(a_hi*SA) * bf16(b_hi*S)                 v_mfma_f32_32x32x16_bf16 : exact products, fp32 exponent range
+//   acc += f16(a*SA)     * f16(b_lo*S)                  v_mfma_f32_32x32x16_f16
+//   acc += f16(a_lo*SA)  * f16(b_hi*S)                  v_mfma_f32_32x32x16_f16      S = 2^8 (static, weights), SA = 2^sa (per launch)
+//   result = acc / (S*SA)                               (folded into the epilogue's alpha; all three terms carry the same scale)
+//   The cross terms are <= 2^-8 of the product and carry 11-bit operands: operand error ~2^-21 of the tensor's scale -- the
+//   size of a plain fp32 GEMM's accumulation error.  The powers of two keep the fp16 operands in range: S lifts the weight
+//   tails (~2^-9 |w|) out of the fp16 subnormals, SA brings an A tensor of unknown scale (the cotangents of the VJP) to O(1);
+//   conversions round to nearest and SATURATE at +-65504 (v_cvt_pk_f16_f32 + packed min / max): an
+//   element outside the fp16 window loses (part of) its cross terms, i.e. degrades towards the bf16 head's 2^-9, never to inf.
+//   A planes in LDS: bf16 a_hi*SA | f16 a*SA | f16 a_lo*SA; B planes (packed weights): bf16 b_hi*S | f16 b_lo*S, and the
+//   scaled head is re-encoded bf16 -> f16 in registers (exact: 8 significant bits, |w * 2^8| < 65504).
+// KDIP_X3_MIXED 0: plain bf16 split, a_hi*b_hi + a_hi*bf16(b_lo) + bf16(a_lo)*b_hi: operand error ~2^-18 (8 x the mixed
+//   form's), no range window at all.
+#ifndef KDIP_X3_MIXED
+#define KDIP_X3_MIXED 1
+#endif
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr float X3_S = KDIP_X3_MIXED ? 256.f : 1.f;
+// two fp32 -> packed f16x2: round toward zero (exact for operands that fit; 1 instruction)
+__device__ __forceinline__ uint32_t pack_f16x2_rtz(float lo, float hi) { return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(lo, hi)); }
+// ... round to nearest even, saturating at +-65504 (v_cvt_pk_f16_f32 + v_pk_min_f16 + v_pk_max_f16: inf -> largest finite)
+__device__ __forceinline__ uint32_t pack_f16x2_sat(float lo, float hi) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const f2 v = {lo, hi};
+  const h2 lim = {(_Float16)65504.f, (_Float16)65504.f};
+  h2 h = __builtin_convertvector(v, h2);
+  h = __builtin_elementwise_max(__builtin_elementwise_min(h, lim), -lim);
+  return __builtin_bit_cast(uint32_t, h);
+}
+__device__ __forceinline__ uint4 bf16x8_to_f16x8(const uint4& v) {        // exact for 8-bit significands inside the fp16 range
+  return make_uint4(pack_f16x2_rtz(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u)),
+                    pack_f16x2_rtz(__uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u)),
+                    pack_f16x2_rtz(__uint_as_float(v.z << 16), __uint_as_float(v.z & 0xffff0000u)),
+                    pack_f16x2_rtz(__uint_as_float(v.w << 16), __uint_as_float(v.w & 0xffff0000u)));
+}
 template <> struct Mma<f32x3_t> {
   static constexpr int KSTEP = 16;
-  static constexpr int NP = 2, NTERM = 3;
-  template <int TERM> __device__ static inline void run(const uint4 (&a)[2], const uint4 (&b)[2], f32x16& c) {
+  static constexpr int NPA = KDIP_X3_MIXED ? 3 : 2, NPB = 2, NTERM = 3, LDS_BPC = 2 * NPA;
+  // bh: plane 0 of b re-encoded as f16 (mixed form only)
+  template <int TERM> __device__ static inline void run(const uint4 (&a)[NPA], const uint4 (&b)[2], const uint4& bh, f32x16& c) {
+#if KDIP_X3_MIXED
+    if constexpr (TERM == 0)
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, b[0]), c, 0, 0, 0);
+    else if constexpr (TERM == 1)
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[1]), __builtin_bit_cast(f16x8, b[1]), c, 0, 0, 0);
+    else
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[2]), __builtin_bit_cast(f16x8, bh), c, 0, 0, 0);
+#else
     constexpr int pa = TERM == 2 ? 1 : 0, pb = TERM == 1 ? 1 : 0;
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[pa]), __builtin_bit_cast(bf16x8, b[pb]), c, 0, 0, 0);
+#endif
   }
 };
 
@@ -93,6 +142,7 @@ struct ConvParams {
   const void* st_x; long st_ldx;  // mode 2
   const float* st_coef;           // mode 2: [B][Cout][2] (a, b)
   const float* st_mr;             // mode 2: [B][32][2] (mean, rstd)
+  const unsigned* x3_amax;        // split precision: optional device word = bits of max |x| of the input's tensor family (sets the fp16 window of the A operand)
   unsigned long long* dbg;        // KDIP_TIMING builds: [grid][8] s_memrealtime stamps (start, staged, k-loop done, end, store loop done, sync 1, sync 2)
 };
 
@@ -176,10 +226,15 @@ constexpr int KC = 32;            // input channels per B-pipeline stage (one ta
 #define KDIP_OCC 3
 #endif
 #ifndef KDIP_X3_OCC
-#define KDIP_X3_OCC 2        // split-precision instantiations: resident blocks per CU the register budget is set for
+#define KDIP_X3_OCC 2        // split-precision 128x128 tiles: resident blocks per CU the register budget is set for
+#endif
+#ifndef KDIP_X3_SUBS1
+#define KDIP_X3_SUBS1 1      // split-precision 1x1 convs: 32-channel sub-chunks staged per barrier (2 = 102 KB of LDS, one block per CU: 404 vs 249 us
+                             // on the 128 -> 256 @ 256x256 skip conv)
 #endif
 #ifndef KDIP_X3_B_DEPTH
-#define KDIP_X3_B_DEPTH 1    // ... and their weight-fragment stages in flight (two 16-byte planes per fragment)
+#define KDIP_X3_B_DEPTH 2    // ... and the weight-fragment stages in flight of their 3x3 instantiations (two 16-byte planes per fragment): 2 measured
+                             // +4 - 6 % over 1 on the large maps; the 1x1 instantiations keep 1 (-6 % with 2)
 #endif
 
 
@@ -347,17 +402,18 @@ __device__ __forceinline__ void epilogue_bf16_fast(const ConvParams& p, f32x16 (
 // SUBS = 32-channel sub-chunks staged in LDS per barrier (1 for 3x3; up to 4 for 1x1 so a barrier
 // covers 32 MFMAs per wave instead of 8).
 template <typename T, int NTAPS, int WAVES_M, int WAVES_N, int MT, int NT, int SUBS>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::value) ? KDIP_X3_OCC : (sizeof(T) == 2 && NTAPS == 9) ? (MT * NT == 4 ? KDIP_OCC : (MT * NT == 8 ? 2 : 1)) : ((sizeof(T) == 2 && NTAPS == 1 && MT * NT == 4 && SUBS == 2) ? 3 : 1)) void conv_igemm_kernel(ConvParams p) {
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::value) ? (MT * NT == 4 ? KDIP_X3_OCC : 2) : (sizeof(T) == 2 && NTAPS == 9) ? (MT * NT == 4 ? KDIP_OCC : (MT * NT == 8 ? 2 : 1)) : ((sizeof(T) == 2 && NTAPS == 1 && MT * NT == 4 && SUBS == 2) ? 3 : 1)) void conv_igemm_kernel(ConvParams p) {
   constexpr bool X3 = std::is_same<T, f32x3_t>::value;     // fp32 storage, operands split into bf16 hi / lo planes on the way into LDS
-  constexpr int NP = Mma<T>::NP, NTERM = Mma<T>::NTERM;
+  constexpr int NPA = Mma<T>::NPA, NPB = Mma<T>::NPB, NTERM = Mma<T>::NTERM;
+  constexpr bool X3M = X3 && KDIP_X3_MIXED;                // bf16 head + fp16 tails
   constexpr int NTHREADS = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * MT * 32;
   constexpr int BN = WAVES_N * NT * 32;
   constexpr int KSTEP = Mma<T>::KSTEP;
   constexpr int KS = KC / KSTEP;                       // k-steps per 32-channel sub-chunk
   constexpr int KCH = KC * SUBS;                       // channels per LDS stage
-  constexpr int PIXB = KCH * (int)sizeof(T) + 16;      // padded LDS pixel stride (bytes)
-  constexpr int VPP = KCH * (int)sizeof(T) / 16;       // 16-byte vectors per staged pixel
+  constexpr int PIXB = KCH * Mma<T>::LDS_BPC + 16;     // padded LDS pixel stride (bytes)
+  constexpr int VPP = KCH * (int)sizeof(T) / 16;       // 16-byte vectors per staged pixel (global side)
   constexpr int NST = NTAPS * SUBS;                    // B-pipeline stages per LDS stage
   // stage index after which the next patch is written to the other LDS buffer (0 = at the chunk end)
   constexpr int EW_AT = (!KDIP_EARLY_WRITE || NST == 1) ? 0 : (NST >= 9 ? KDIP_EARLY_WRITE : NST / 2);
@@ -469,14 +525,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
   const int nt0 = ntb * (BN / 32) + wn * NT;           // first n-tile of this wave
   const uint4* wp = (const uint4*)p.wp;
   const long kstepsTotal = (long)(p.Cin / KSTEP);
-  const long kStride = (long)p.ntilesN * 64 * NP;      // uint4 per k-step ([n-tile][plane][lane])
+  const long kStride = (long)p.ntilesN * 64 * NPB;     // uint4 per k-step ([n-tile][plane][lane])
   const long tapStride = kstepsTotal * kStride;        // uint4 per tap
   const uint4* wbase[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     int ntile = nt0 + nt;
     ntile = ntile < p.ntilesN ? ntile : p.ntilesN - 1;  // clamp (results discarded)
-    wbase[nt] = wp + (long)ntile * 64 * NP;
+    wbase[nt] = wp + (long)ntile * 64 * NPB;
   }
   auto bptr = [&](int tap, long kstep, int nt) -> const uint4* {
     return wbase[nt] + (tap * tapStride + kstep * kStride) + lane;
@@ -489,6 +545,20 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+  // fp16 window of the A operand (mixed split-precision form): SA = 2^sa brings the launch's input tensor to O(1).  sa = 0
+  // unless the caller names a device word holding the bits of max |x| of the tensor family this input belongs to (the VJP's
+  // cotangent): then sa = -(its exponent).  The accumulators carry the scale S*SA; it leaves with the epilogue's alpha.
+  float x3_sa = 1.f;
+  float alpha = X3 ? p.alpha * (1.f / X3_S) : p.alpha;
+  const bool x3_scaled = X3M && p.x3_amax != nullptr;
+  if (x3_scaled) {
+    const unsigned bits = __builtin_nontemporal_load(p.x3_amax);
+    int e = (int)((bits >> 23) & 0xff) - 127;
+    if (bits == 0u) e = 0;
+    e = e < -60 ? -60 : (e > 60 ? 60 : e);
+    x3_sa = __uint_as_float((unsigned)(127 - e) << 23);
+    alpha *= __uint_as_float((unsigned)(127 + e) << 23);
+  }
 
   const int nchunks_all = p.Cin / KCH;
   // split-K: this block's chunk range [c_begin, c_end); one range = everything otherwise
@@ -520,12 +590,21 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
         if (pix < npix) {
           float f[4];
           unpack16<float>(areg[i], f);
+          if (x3_scaled) {                               // (block-uniform) exact power-of-two scaling
+#pragma unroll
+            for (int e = 0; e < 4; ++e) f[e] *= x3_sa;
+          }
           const uint32_t h0 = pack_bf16x2(f[0], f[1]), h1 = pack_bf16x2(f[2], f[3]);
-          const uint32_t l0 = pack_bf16x2(f[0] - __uint_as_float(h0 << 16), f[1] - __uint_as_float(h0 & 0xffff0000u));
-          const uint32_t l1 = pack_bf16x2(f[2] - __uint_as_float(h1 << 16), f[3] - __uint_as_float(h1 & 0xffff0000u));
+          const float r0 = f[0] - __uint_as_float(h0 << 16), r1 = f[1] - __uint_as_float(h0 & 0xffff0000u);
+          const float r2 = f[2] - __uint_as_float(h1 << 16), r3 = f[3] - __uint_as_float(h1 & 0xffff0000u);
           unsigned char* d = smem + buf * abuf_bytes + pix * PIXB + (v % VPP) * 8;
           *(uint2*)d = make_uint2(h0, h1);
-          *(uint2*)(d + KCH * 2) = make_uint2(l0, l1);
+          if constexpr (X3M) {
+            *(uint2*)(d + KCH * 2) = make_uint2(pack_f16x2_sat(f[0], f[1]), pack_f16x2_sat(f[2], f[3]));
+            *(uint2*)(d + KCH * 4) = make_uint2(pack_f16x2_sat(r0, r1), pack_f16x2_sat(r2, r3));
+          } else {
+            *(uint2*)(d + KCH * 2) = make_uint2(pack_bf16x2(r0, r1), pack_bf16x2(r2, r3));
+          }
         }
       } else {
         if (pix < npix) *(uint4*)(smem + buf * abuf_bytes + pix * PIXB + (v % VPP) * 16) = areg[i];
@@ -537,7 +616,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
   // registers; a stage index past the end is clamped to the last stage (one redundant L2 hit) so the
   // loop body has no branches.
   const int nstages = nchunks_all * SUBS * NTAPS;
-  auto load_b = [&](uint4 (&dst)[KS][NT][NP], int stage) {
+  auto load_b = [&](uint4 (&dst)[KS][NT][NPB], int stage) {
     stage = stage < nstages ? stage : nstages - 1;
     const int c32 = stage / NTAPS, tp = stage - c32 * NTAPS;
 #pragma unroll
@@ -545,10 +624,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int pl = 0; pl < NP; ++pl) dst[ks][nt][pl] = bptr(tp, (long)c32 * KS + ks, nt)[pl * 64];
+        for (int pl = 0; pl < NPB; ++pl) dst[ks][nt][pl] = bptr(tp, (long)c32 * KS + ks, nt)[pl * 64];
   };
-  constexpr int BD = X3 ? KDIP_X3_B_DEPTH : (MT * NT <= 2 && sizeof(T) == 2 && NTAPS == 9) ? KDIP_B_DEPTH_SMALL : KDIP_B_DEPTH;   // stages ahead
-  uint4 bq[BD + 1][KS][NT][NP];
+  constexpr int BD = X3 ? (NTAPS == 9 ? KDIP_X3_B_DEPTH : 1) : (MT * NT <= 2 && sizeof(T) == 2 && NTAPS == 9) ? KDIP_B_DEPTH_SMALL : KDIP_B_DEPTH;   // stages ahead
+  uint4 bq[BD + 1][KS][NT][NPB];
 
   // prologue: the first two B stages are requested together with the first patch, ahead of the LDS write + barrier
   // (issued after the barrier their L2 latency sat exposed in front of the first MFMA)
@@ -563,16 +642,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
 
   // A fragments of the next (sub, tap) stage are read from LDS one stage ahead, so the ds_reads
   // of stage s+1 are in flight under the MFMAs of stage s.
-  auto load_a = [&](uint4 (&dst)[KS][MT][NP], const unsigned char* abuf, int sub, int tap) {
+  auto load_a = [&](uint4 (&dst)[KS][MT][NPA], const unsigned char* abuf, int sub, int tap) {
     const int toff = ((NTAPS == 9) ? ((tap / 3) * HW_ + (tap % 3)) * PIXB : 0) + sub * KC * (X3 ? 2 : (int)sizeof(T));
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int pl = 0; pl < NP; ++pl) dst[ks][mt][pl] = *(const uint4*)(abuf + abase[mt] + toff + ks * 32 + pl * (KCH * 2));
+        for (int pl = 0; pl < NPA; ++pl) dst[ks][mt][pl] = *(const uint4*)(abuf + abase[mt] + toff + ks * 32 + pl * (KCH * 2));
   };
-  uint4 aq0[KS][MT][NP], aq1[KS][MT][NP];
+  uint4 aq0[KS][MT][NPA], aq1[KS][MT][NPA];
   // what the staging slots of chunk c fetch: the next chunk of this tile, or (last chunk of a prefetching tile) chunk 0 of
   // the block's next tile -- from then on goff describes that tile
   auto next_load = [&](int c) {
@@ -607,26 +686,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
         if (KDIP_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
+          uint4 bh[NT];                                  // mixed split precision: the weight head re-encoded as f16 (once per fragment)
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) Mma<T>::template run<0>(aq0[ks][mt], bq[0][ks][nt], acc[mt][nt]);
-          if constexpr (NTERM > 1) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-              for (int nt = 0; nt < NT; ++nt) Mma<T>::template run<1>(aq0[ks][mt], bq[0][ks][nt], acc[mt][nt]);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-              for (int nt = 0; nt < NT; ++nt) Mma<T>::template run<2>(aq0[ks][mt], bq[0][ks][nt], acc[mt][nt]);
-          }
-          if constexpr (NTERM > 3) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-              for (int nt = 0; nt < NT; ++nt) Mma<T>::template run<3>(aq0[ks][mt], bq[0][ks][nt], acc[mt][nt]);
-          }
+          for (int nt = 0; nt < NT; ++nt) bh[nt] = X3M ? bf16x8_to_f16x8(bq[0][ks][nt][0]) : make_uint4(0, 0, 0, 0);
+#define KDIP_MMA_PASS(TERM)                                                                                      \
+          _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                      \
+          _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                      \
+            Mma<T>::template run<TERM>(aq0[ks][mt], bq[0][ks][nt], bh[nt], acc[mt][nt]);
+          KDIP_MMA_PASS(0)
+          if constexpr (NTERM > 1) { KDIP_MMA_PASS(1) KDIP_MMA_PASS(2) }
+          if constexpr (NTERM > 3) { KDIP_MMA_PASS(3) }
+#undef KDIP_MMA_PASS
         }
         if (KDIP_SETPRIO) __builtin_amdgcn_s_setprio(0);
         if (!KDIP_ABL_NOSTAGE && NTAPS * SUBS > 1 && sub == 0 && tap == 0) next_load(c);
@@ -640,13 +710,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
 #pragma unroll
             for (int i = 0; i < BD; ++i)
 #pragma unroll
-              for (int pl = 0; pl < NP; ++pl) bq[i][ks][nt][pl] = bq[i + 1][ks][nt][pl];
+              for (int pl = 0; pl < NPB; ++pl) bq[i][ks][nt][pl] = bq[i + 1][ks][nt][pl];
           }
           if (KDIP_A_PREFETCH) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-              for (int pl = 0; pl < NP; ++pl) aq0[ks][mt][pl] = aq1[ks][mt][pl];
+              for (int pl = 0; pl < NPA; ++pl) aq0[ks][mt][pl] = aq1[ks][mt][pl];
           }
         }
         if (!KDIP_A_PREFETCH) {
@@ -691,7 +761,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
           const int ty = rr >> p.lgTW, tx = rr & (p.TW - 1);
           const int gb = img0 + tb;
           if (n < p.Cout && gb < p.B)
-            atomicAdd(p.sk_ws + (((long)gb * p.H + (y0 + ty)) * p.W + (x0 + tx)) * p.Cout + n, acc[mt][nt][r] * p.alpha);
+            atomicAdd(p.sk_ws + (((long)gb * p.H + (y0 + ty)) * p.W + (x0 + tx)) * p.Cout + n, acc[mt][nt][r] * alpha);
         }
     }
     KDIP_STAMP(3);
@@ -747,7 +817,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          *(float*)(creg + row * RS + (nt * 32 + (lane & 31)) * 4) = acc[mt][nt][r] * p.alpha + bv;
+          *(float*)(creg + row * RS + (nt * 32 + (lane & 31)) * 4) = acc[mt][nt][r] * alpha + bv;
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -854,7 +924,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
         int gb = img0 + tb;
         if (!nok || gb >= p.B) continue;
         long pix = ((long)gb * p.H + (y0 + ty)) * p.W + (x0 + tx);
-        float v = acc[mt][nt][r] * p.alpha + bv;
+        float v = acc[mt][nt][r] * alpha + bv;
         if (res) {
           const long rpix = p.res_ups ? ((long)gb * (p.H >> 1) + ((y0 + ty) >> 1)) * (p.W >> 1) + ((x0 + tx) >> 1) : pix;
           v += to_f32(res[rpix * p.ldr + n]);
@@ -890,7 +960,7 @@ __global__ void conv_splitk_finalize_kernel(float* __restrict__ ws, const float*
 template <typename T, int NTAPS, int WAVES_M, int WAVES_N, int MT, int NT, int SUBS>
 static int launch_cfg2(ConvParams& p, hipStream_t st) {
   constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32;
-  constexpr int PIXB = KC * SUBS * (int)sizeof(T) + 16;
+  constexpr int PIXB = KC * SUBS * Mma<T>::LDS_BPC + 16;
   constexpr int HALO = (NTAPS == 9) ? 1 : 0;
   // 32-pixel-wide patches: an MFMA m-tile (32 rows) is one patch row, so the 16-lane groups of
   // ds_read_b128 see 16 consecutive pixels (5-slot stride -> conflict free); 16-wide patches put two
@@ -947,7 +1017,7 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
     KDIP_HIP_CHECK(hipGetDevice(&dev));
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(granted.load(std::memory_order_acquire) & bit)) {
-      KDIP_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024)));
+      KDIP_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((std::is_same<T, f32x3_t>::value ? 128 : 96) * 1024)));
       granted.fetch_or(bit, std::memory_order_release);
     }
   }
@@ -1013,7 +1083,7 @@ static int launch_cfg(ConvParams& p, hipStream_t st) {
     if (KDIP_SUBS1 >= 4 && sizeof(T) == 2 && p.Cin % 128 == 0) return launch_cfg2<T, NTAPS, WAVES_M, WAVES_N, MT, NT, (NTAPS == 1 ? 4 : 1)>(p, st);
     if (KDIP_SUBS1 >= 2 && sizeof(T) == 2 && p.Cin % 64 == 0) return launch_cfg2<T, NTAPS, WAVES_M, WAVES_N, MT, NT, (NTAPS == 1 ? 2 : 1)>(p, st);
     // split precision: 64 channels (12 MFMAs per accumulator) per barrier
-    if (std::is_same<T, f32x3_t>::value && p.Cin % 64 == 0) return launch_cfg2<T, NTAPS, WAVES_M, WAVES_N, MT, NT, (NTAPS == 1 ? 2 : 1)>(p, st);
+    if (KDIP_X3_SUBS1 >= 2 && std::is_same<T, f32x3_t>::value && p.Cin % 64 == 0) return launch_cfg2<T, NTAPS, WAVES_M, WAVES_N, MT, NT, (NTAPS == 1 ? 2 : 1)>(p, st);
   }
 #if KDIP_SUBS3 > 1
   if (NTAPS == 9 && sizeof(T) == 2 && MT * NT == 4 && p.Cin % (32 * KDIP_SUBS3) == 0)
@@ -1058,6 +1128,7 @@ int conv_forward(hipStream_t st, DType dt, int ntaps, const void* x, long ldx, i
   p.out_f32 = out_f32; p.alpha = alpha; p.cin_real = cin_real > 0 ? cin_real : Cin;
   p.st_mode = 0; p.st_silu = 0; p.st_sums = nullptr; p.st_x = nullptr; p.st_ldx = 0; p.st_coef = nullptr; p.st_mr = nullptr;
   p.in_ups = stt ? stt->in_ups : 0; p.res_ups = stt ? stt->res_ups : 0;
+  p.x3_amax = stt ? stt->x3_amax : nullptr;
   p.sk_ws = sk_ws; p.sk_ws_floats = sk_ws_floats; p.sk_splits = 1;
   KDIP_REQUIRE(!(p.in_ups || p.res_ups) || (H % 2 == 0 && W % 2 == 0), "conv: fused x2 upsample needs even H, W");
   if (stt && stt->mode) {
@@ -1074,10 +1145,31 @@ int conv_forward(hipStream_t st, DType dt, int ntaps, const void* x, long ldx, i
 // transpose_flip: build the dgrad weight W'[ci][co][ky][kx] = W[co][ci][kh-1-ky][kw-1-kx].
 // Output element (tap, kstep, ntile, lane, e) = W[n][k][tap], n = ntile*32 + (lane&31),
 // k = kstep*KSTEP + (lane>>5)*EPL + e; zero outside [Cout) x [Cin).
-// DT_F32X3: (tap, kstep, ntile, plane, lane, e) with plane 0 = bf16(W), plane 1 = bf16(W - plane 0), bf16 k-steps.
+// DT_F32X3: (tap, kstep, ntile, plane, lane, e) with plane 0 = bf16(W * 2^8), plane 1 = f16(W * 2^8 - plane 0) (mixed form; plain
+// form: bf16(W), bf16(W - plane 0)), 16-channel k-steps.
 size_t packed_weight_bytes(DType dt, int ntaps, int Cin_pad, int Cout) {
   size_t es = dt == DT_BF16 ? 2 : 4;
   return (size_t)ntaps * Cin_pad * cdiv(Cout, 32) * 32 * es;
+}
+
+// host fp32 -> IEEE binary16 bits, round-to-nearest-even, saturating (no inf)
+static uint16_t f32_to_f16_bits(float f) {
+  union { float f; uint32_t u; } c; c.f = f;
+  const uint32_t sign = (c.u >> 16) & 0x8000u;
+  float a = fabsf(f);
+  if (!(a == a)) return (uint16_t)(sign | 0x7e00u);
+  if (a >= 65504.f) return (uint16_t)(sign | 0x7bffu);
+  if (a < 6.103515625e-05f) {                     // subnormal: multiples of 2^-24
+    const float q = a * 16777216.f;               // exact scaling
+    const float r = nearbyintf(q);                // default rounding mode: to nearest even
+    return (uint16_t)(sign | (uint32_t)r);        // r == 1024 lands on the smallest normal, as it should
+  }
+  c.f = a;
+  uint32_t u = c.u;
+  u += 0xfffu + ((u >> 13) & 1u);                 // round the 13 dropped mantissa bits to nearest even
+  const uint32_t e = (u >> 23) - 127 + 15, m = (u >> 13) & 0x3ffu;
+  if (e >= 31) return (uint16_t)(sign | 0x7bffu);
+  return (uint16_t)(sign | (e << 10) | m);
 }
 
 void pack_conv_weight(DType dt, const float* w, int Cout, int Cin, int ntaps, int transpose_flip, int Cin_pad_out,
@@ -1099,10 +1191,11 @@ void pack_conv_weight(DType dt, const float* w, int Cout, int Cin, int ntaps, in
         for (int nt = 0; nt < ntiles; ++nt, idx += 2 * 64 * 8)
           for (int lane = 0; lane < 64; ++lane)
             for (int e = 0; e < 8; ++e) {
-              const float v = W(nt * 32 + (lane & 31), ks * 16 + (lane >> 5) * 8 + e, tap);
+              const float v = W(nt * 32 + (lane & 31), ks * 16 + (lane >> 5) * 8 + e, tap) * X3_S;     // exact power-of-two scaling
               const bf16_t hi = f32_to_bf16(v);
               o[idx + lane * 8 + e] = hi;
-              o[idx + 64 * 8 + lane * 8 + e] = f32_to_bf16(v - bf16_to_f32(hi));
+              const float lo = v - bf16_to_f32(hi);
+              o[idx + 64 * 8 + lane * 8 + e] = KDIP_X3_MIXED ? f32_to_f16_bits(lo) : f32_to_bf16(lo);
             }
     return;
   }

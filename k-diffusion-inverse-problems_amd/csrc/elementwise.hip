@@ -112,6 +112,24 @@ __global__ void silu_f32_kernel(const float* x, long n, float* y) {
     y[i] = z / (1.f + expf(-z));
   }
 }
+__global__ void amax_bits_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
+  unsigned m = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const unsigned b = __float_as_uint(x[i]) & 0x7fffffffu;
+    if (b < 0x7f800000u && b > m) m = b;          // finite values only
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const unsigned t = __shfl_xor(m, o, 64); m = t > m ? t : m; }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+int amax_bits(hipStream_t st, const float* x, long n, unsigned* out) {
+  KDIP_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(unsigned), st));
+  long g = (n + 256 * 8 - 1) / (256 * 8); if (g > 1024) g = 1024; if (g < 1) g = 1;
+  hipLaunchKernelGGL(amax_bits_kernel, dim3((unsigned)g), dim3(256), 0, st, x, n, out);
+  KDIP_LAUNCH_CHECK();
+  return KDIP_OK;
+}
+
 int silu_f32(hipStream_t st, const float* x, long n, float* y) {
   hipLaunchKernelGGL(silu_f32_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x, n, y);
   KDIP_LAUNCH_CHECK();

@@ -14,6 +14,9 @@ struct ConvStats {
   // nearest-neighbour x2 upsampling folded into the reads (Upsample of an upsampling ResBlock, unet.py:232-235): the input
   // tensor / the residual tensor are HALF-resolution [B, H/2, W/2, C] and pixel (y, x) reads (y >> 1, x >> 1)
   int in_ups = 0, res_ups = 0;
+  // split-precision mode (DT_F32X3): device word holding the bits of max |x| of the tensor family the INPUT belongs to (the VJP's
+  // cotangent), or null for inputs of O(1) scale (forward activations): sets the fp16 window of the A operand (conv.hip, Mma<f32x3_t>)
+  const unsigned* x3_amax = nullptr;
 };
 // true iff conv_forward can fuse statistics for an output of this shape
 inline bool conv_stats_eligible(int H, int W, int Cout) { return (long)H * W >= 128 && Cout % 128 == 0; }
@@ -129,6 +132,8 @@ int relu_maxpool_planes(hipStream_t st, const float* x, long planes, int H, int 
 int lpips_layer(hipStream_t st, const float* f0, const float* f1, const float* w, int B, int C, long HW, float* out);
 int gauss_nll_mean(hipStream_t st, const float* pred, const float* target, const float* logvar, int B, long per, int accumulate, float* out);
 int silu_f32(hipStream_t st, const float* x, long n, float* y);
+// *out = bits of max |x| (fp32 bit patterns of non-negative floats order like unsigned integers); capture-safe (memset + one kernel)
+int amax_bits(hipStream_t st, const float* x, long n, unsigned* out);
 int timestep_embedding(hipStream_t st, const float* t, int B, int dim, float* out);
 int f32_to_T(hipStream_t st, DType dt, const float* x, long n, void* y);
 int T_to_f32(hipStream_t st, DType dt, const void* x, long n, float* y);

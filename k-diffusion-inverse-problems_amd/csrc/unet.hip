@@ -257,6 +257,10 @@ int UNet::finalize() {
     mkconv(cov_conv, "out_cov", final_ch, 6, 1);   // OpenAIDenoiserV2.out_cov (k_diffusion/external.py:141)
     has_cov = true;
   }
+  if (!rc && cdt == DT_F32X3) {
+    const unsigned zero = 0;
+    x3_amax = (unsigned*)upload(&zero, sizeof(zero));
+  }
   if (rc) return rc;
   raw.clear();
   finalized = true;
@@ -433,13 +437,14 @@ int conv_b(Ctx& c, const ConvW& w, const void* g, long ldg, int B, int H, int W,
   }
   if (tf2_coef) return set_error(KDIP_ERR_STATE, "internal: fused GroupNorm-backward staging requested for a conv the second-generation kernel cannot run");
   ConvStats stt;
+  stt.x3_amax = c.u->x3_amax;          // (split-precision mode) gradients have no natural scale: the window follows this VJP's cotangent
   if (stats_ok) {
     stt.mode = 2; stt.silu = gn_silu; stt.x = gn_x; stt.ldx = gn_ldx; stt.coef = gn_coef; stt.mr = gn_mr;
     stt.sums = new_sums(c, B);
     *sums_out = stt.sums;
   }
   RUN(conv_forward(c.st, c.cdt(), w.ntaps, g, ldg, B, H, W, w.cin_pad_b, w.wb, nullptr, w.cin, y, ldy, res, ldr, out_f32, 1.f, w.cout,
-                   stt.mode ? &stt : nullptr, c.u->sk_ws, c.u->sk_ws_floats));
+                   (stt.mode || stt.x3_amax) ? &stt : nullptr, c.u->sk_ws, c.u->sk_ws_floats));
   return KDIP_OK;
 }
 }  // namespace
@@ -828,6 +833,7 @@ int UNet::vjp_impl(hipStream_t st, const float* cot_nchw, float* gx_nchw) {
   // cotangent NCHW fp32 [B,out_ch,H,W] -> NHWC T padded to 32 channels
   void* cot = persist.alloc(es * B * HW0 * 32);
   RUN(nchw_to_nhwc(st, dt, cot_nchw, B, cfg.out_channels, H0, W0, 1.f, cot, 32, 32));
+  if (x3_amax) RUN(amax_bits(st, cot_nchw, (long)B * cfg.out_channels * HW0, x3_amax));
   void* ghn = scratch.alloc(es * B * HW0 * final_ch);
   double* sumsh = nullptr;
   int gh_dz = 0;
