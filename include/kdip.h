@@ -107,6 +107,9 @@ int kdip_op_set_cg_fixed_trips(kdip_op* op, int trips);
  * (sticky device counter, read + cleared here; synchronises the stream).  Callers that replay captured guided calls check it once
  * per sampler run instead of reading flags every second CG iteration. */
 int kdip_op_cg_unconverged(kdip_op* op, void* stream, int* count_host);
+/* Bumped whenever the operator re-allocates its solver workspace (a call at a larger batch): hipGraphs captured before hold the old
+ * buffers (same contract as kdip_unet_workspace_generation). */
+long kdip_op_workspace_generation(kdip_op* op);
 /* OrthoTransform.__call__ / .inv on [B,3,S,S] (condition/utils.py:59-67,88-139). */
 int kdip_op_ortho(kdip_op* op, void* stream, const float* x_dev, int B, int inverse, float* out_dev);
 
@@ -209,6 +212,12 @@ int kdip_debug_cu_census(void* stream, int blocks, unsigned* out_host);
  * (ignored when tensor_var: the learned per-pixel variance is used), ws_dev = kdip_guided_ws_floats(B, S) floats, hat_dev [B,3,S,S].
  * Capture-safe when the operator is in fixed-trip CG mode (or tensor_var == 0).  Leaves the UNet stash valid for kdip_unet_vjp. */
 long kdip_guided_ws_floats(int B, int S);
+/* Regions of that workspace after a call, as float offsets from ws_dev: offsets_host[KDIP_GWS_*] (count must be KDIP_GWS_COUNT).
+ * x0_raw (the un-clamped x0 prediction) is what a stepwise continuation needs for another VJP through the clamp
+ * (condition.py:231 `pred_xstart.clamp(-1, 1)`; tmpd :268-269, STSL :185-208). */
+enum { KDIP_GWS_OUT6 = 0, KDIP_GWS_X0_MEAN, KDIP_GWS_X0_RAW, KDIP_GWS_VAR, KDIP_GWS_MAT, KDIP_GWS_COT, KDIP_GWS_G_RAW, KDIP_GWS_UG,
+       KDIP_GWS_SCORE, KDIP_GWS_COUNT };
+int kdip_guided_ws_layout(int B, int S, long* offsets_host, int count);
 int kdip_guided_call_v1(kdip_unet* u, kdip_op* op, void* stream, const float* x_dev, const float* t_dev, const float* y_dev, int B,
                         const float* tables7_host, float sigma, float var_scalar, int tensor_var, float* ws_dev, float* hat_dev,
                         int* cg_iters_host, int* cg_info_host);
@@ -242,9 +251,6 @@ int kdip_test_groupnorm(void* stream, int dtype, const float* x_nchw_dev, int B,
 int kdip_debug_conv_timing(void* dev_buf, int H, int cin, int cout, int st_mode);
 /* Same for csrc/conv3.hip (-DC3_TIMING=1): dev_buf[grid][8] = start, first patch staged, K loop done, end (100 MHz ticks), XCC id. */
 int kdip_debug_conv3_timing(void* dev_buf);
-/* Test / A-B aid: which bf16 3x3 kernel generation runs the large-map convs: 0 = automatic (conv4.hip where a launch has enough
- * 16 x 32-pixel tiles to fill the chip, else conv3.hip), 3 = conv3.hip only, 4 = conv4.hip wherever the shape allows.  Process-wide. */
-int kdip_debug_conv_generation(int gen);
 /* Test / A-B aid: 1 (default) = the large-map bf16 convs compute their GroupNorm staging coefficients from the statistics themselves
  * (no gn_coef / gn_merge_stats / gn_bwd_coef launches between two convs); 0 = separate coefficient kernels.  Results are bit-identical. */
 int kdip_debug_gn_fold(int on);

@@ -40,6 +40,8 @@ SIGNATURES = {
     "kdip_stream_destroy": (C.c_int, [VP]),
     "kdip_debug_cu_census": (C.c_int, [VP, C.c_int, VP]),
     "kdip_guided_ws_floats": (C.c_long, [C.c_int, C.c_int]),
+    "kdip_guided_ws_layout": (C.c_int, [C.c_int, C.c_int, VP, C.c_int]),
+    "kdip_op_workspace_generation": (C.c_long, [VP]),
     "kdip_guided_call_v1": (C.c_int, [VP, VP, VP, VP, VP, VP, C.c_int, VP, C.c_float, C.c_float, C.c_int, VP, VP, VP, VP]),
     "kdip_gather": (C.c_int, [VP, VP, VP, C.c_long, C.c_long, C.c_int, VP]),
     "kdip_scatter": (C.c_int, [VP, VP, VP, C.c_long, C.c_long, C.c_int, VP]),
@@ -74,7 +76,6 @@ SIGNATURES = {
     "kdip_debug_conv_timing": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, C.c_int]),
     "kdip_test_conv": (C.c_int, [VP, C.c_int, C.c_int, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, C.c_int, C.c_int, VP, C.c_int]),
     "kdip_debug_conv3_timing": (C.c_int, [VP]),
-    "kdip_debug_conv_generation": (C.c_int, [C.c_int]),
     "kdip_debug_gn_fold": (C.c_int, [C.c_int]),
     "kdip_test_attention": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_int, VP, VP]),
     "kdip_test_conv3": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, C.c_int, C.c_int, C.c_int, VP, VP, C.c_int, C.c_int,
@@ -85,6 +86,7 @@ SIGNATURES = {
 F32, BF16, BF16X3 = 0, 1, 2
 DTYPES = {"f32": F32, "bf16": BF16, "bf16x3": BF16X3}      # include/kdip.h: KDIP_F32 / KDIP_BF16 / KDIP_BF16X3
 OP_INPAINT, OP_BLUR, OP_SR = 0, 1, 2
+GWS_OUT6, GWS_X0_MEAN, GWS_X0_RAW, GWS_VAR, GWS_MAT, GWS_COT, GWS_G_RAW, GWS_UG, GWS_SCORE, GWS_COUNT = range(10)      # include/kdip.h KDIP_GWS_*
 OT_NONE, OT_DWT, OT_DCT = 0, 1, 2
 
 _lib = None

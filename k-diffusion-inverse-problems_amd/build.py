@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libkdip_hip.so")
-SOURCES = ["common.cpp", "conv.hip", "conv3.hip", "conv4.hip", "attention.hip", "gemm.hip", "norm.hip", "elementwise.hip", "unet.hip", "fft.hip", "ops.hip",
+SOURCES = ["common.cpp", "conv.hip", "conv3.hip", "attention.hip", "gemm.hip", "norm.hip", "elementwise.hip", "unet.hip", "fft.hip", "ops.hip",
            "solver.hip", "api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 

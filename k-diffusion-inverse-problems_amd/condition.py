@@ -280,9 +280,15 @@ class ConditionOpenAIDenoiser(ConditionDenoiser):
 
     def _type_I_guidance_impl(self, x, sigma):
         ct = self.x0_cov_type
+        # (the fused entry point runs the library's own mat-solver: a solver registered through register_mat_solver, or a
+        #  mat_solver attribute set by the caller, keeps the stepwise path that goes through self.mat_solver)
         if not (self.fused_call and type(self) is ConditionOpenAIDenoiser and self.ortho_tf_type is None and
-                ct in ('convert', 'analytic', 'pgdm', 'dps', 'diffpir') and hasattr(self.operator, "_h")):
+                ct in ('convert', 'analytic', 'pgdm', 'dps', 'diffpir') and hasattr(self.operator, "_h") and
+                getattr(self.mat_solver, "_kdip_builtin", False)):
             return super()._type_I_guidance_impl(x, sigma)
+        S_model = self.inner_model.image_size
+        if tuple(x.shape[1:]) != (3, S_model, S_model):
+            raise ValueError(f"expected x of shape [B, 3, {S_model}, {S_model}] for this UNet, got {tuple(x.shape)}")
         import ctypes as C
         D = self.diffusion
         s = torch.tensor(sigma_host(sigma), dtype=torch.float32)
@@ -308,6 +314,9 @@ class ConditionOpenAIDenoiser(ConditionDenoiser):
         if getattr(self, "_fused_ws_key", None) != key:
             self._fused_ws = torch.empty(int(self.lib.kdip_guided_ws_floats(B, S)), device=x.device)
             self._fused_t = torch.empty(B, device=x.device)
+            off = (C.c_long * L.GWS_COUNT)()
+            L.check(self.lib.kdip_guided_ws_layout(B, S, off, L.GWS_COUNT))
+            self._fused_off = list(off)
             self._fused_ws_key = key
         self._fused_t.fill_(float(t))
         op = self.operator
@@ -321,8 +330,8 @@ class ConditionOpenAIDenoiser(ConditionDenoiser):
         if any(i > 0 for i in op.cg_info):
             warn('CG not converge.')
         # same stash as uncond_pred leaves behind (x0_raw lives in the call's workspace: valid until the next fused call)
-        n3 = 3 * B * S * S
-        self._stash = (self._fused_ws[3 * n3:4 * n3].view(B, 3, S, S), c_in, t7[1], t7[2], B, S * S)
+        n3, o = 3 * B * S * S, self._fused_off[L.GWS_X0_RAW]
+        self._stash = (self._fused_ws[o:o + n3].view(B, 3, S, S), c_in, t7[1], t7[2], B, S * S)
         return hat
 
     def _vjp_x0(self, ghat):
@@ -420,3 +429,7 @@ def motion_blur_mat(operator, y, x0_mean, theta0_var, ortho_tf=OrthoTransform())
 @torch.no_grad()
 def super_resolution_mat(operator, y, x0_mean, theta0_var, ortho_tf=OrthoTransform()):
     return _device_solve(operator, y, x0_mean, theta0_var, ortho_tf)
+
+
+for _f in (inpainting_mat, gaussian_blur_mat, motion_blur_mat, super_resolution_mat):
+    _f._kdip_builtin = True          # solved by the library's own kdip_op_solve: what kdip_guided_call_v1 runs internally

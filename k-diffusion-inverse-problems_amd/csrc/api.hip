@@ -217,6 +217,17 @@ int kdip_op_cg_unconverged(kdip_op* op, void* stream, int* count_host) {
 // One Type-I guided denoiser call in one entry point (the ~10 C calls of kdip_amd.condition._type_I_guidance_impl, same kernels in
 // the same order): UNet forward, p_mean_variance epilogue, mat-solver, cotangent, UNet VJP, likelihood-score assembly, combine.
 long kdip_guided_ws_floats(int B, int S) { return 33L * B * S * S; }
+// workspace regions of kdip_guided_call_v1, in floats from ws_dev (KDIP_GWS_* order); the caller's stepwise continuation (a second
+// VJP for tmpd / STSL after a fused call) reads x0_raw from here instead of knowing the layout
+int kdip_guided_ws_layout(int B, int S, long* offsets, int count) {
+  KDIP_REQUIRE(offsets && count == KDIP_GWS_COUNT && B >= 1 && S >= 1, "guided_ws_layout: bad arguments (count must be KDIP_GWS_COUNT = %d)", KDIP_GWS_COUNT);
+  const long n3 = 3L * B * S * S;
+  offsets[KDIP_GWS_OUT6] = 0;          offsets[KDIP_GWS_X0_MEAN] = 2 * n3;  offsets[KDIP_GWS_X0_RAW] = 3 * n3;
+  offsets[KDIP_GWS_VAR] = 4 * n3;      offsets[KDIP_GWS_MAT] = 5 * n3;      offsets[KDIP_GWS_COT] = 6 * n3;
+  offsets[KDIP_GWS_G_RAW] = 8 * n3;    offsets[KDIP_GWS_UG] = 9 * n3;       offsets[KDIP_GWS_SCORE] = 10 * n3;
+  return KDIP_OK;
+}
+long kdip_op_workspace_generation(kdip_op* op) { return op ? op->c.ws_generation : -1; }
 int kdip_guided_call_v1(kdip_unet* u, kdip_op* op, void* stream, const float* x_dev, const float* t_dev, const float* y_dev, int B,
                         const float* t7, float sigma, float var_scalar, int tensor_var, float* ws, float* hat_dev,
                         int* cg_iters_host, int* cg_info_host) {
@@ -226,15 +237,17 @@ int kdip_guided_call_v1(kdip_unet* u, kdip_op* op, void* stream, const float* x_
   hipStream_t st = ST(stream);
   const int S = u->u.cfg.image_size;
   const long HW = (long)S * S, n3 = 3L * B * HW;
-  float* out6 = ws;                 // [B,6,S,S]
-  float* x0_mean = out6 + 2 * n3;   // [B,3,S,S] each
-  float* x0_raw = x0_mean + n3;
-  float* var = x0_raw + n3;
-  float* mat = var + n3;
-  float* cot = mat + n3;            // [B,6,S,S]
-  float* g_raw = cot + 2 * n3;
-  float* ug = g_raw + n3;
-  float* score = ug + n3;
+  long off[KDIP_GWS_COUNT];
+  API_CK(kdip_guided_ws_layout(B, S, off, KDIP_GWS_COUNT));       // the one definition of the layout
+  float* out6 = ws + off[KDIP_GWS_OUT6];          // [B,6,S,S]
+  float* x0_mean = ws + off[KDIP_GWS_X0_MEAN];    // [B,3,S,S] each
+  float* x0_raw = ws + off[KDIP_GWS_X0_RAW];
+  float* var = ws + off[KDIP_GWS_VAR];
+  float* mat = ws + off[KDIP_GWS_MAT];
+  float* cot = ws + off[KDIP_GWS_COT];            // [B,6,S,S]
+  float* g_raw = ws + off[KDIP_GWS_G_RAW];
+  float* ug = ws + off[KDIP_GWS_UG];
+  float* score = ws + off[KDIP_GWS_SCORE];
   KDIP_HIP_CHECK(hipSetDevice(u->u.device));
   API_CK(u->u.run(st, x_dev, t_dev, B, t7[0], out6, nullptr, nullptr, 1));
   API_CK(kdip_x0_epilogue_v1(stream, out6, x_dev, B, HW, t7, x0_mean, x0_raw, tensor_var ? var : nullptr));
@@ -496,16 +509,8 @@ int kdip_test_conv3(void* stream, const float* x_nchw, const float* x2_nchw, int
   return KDIP_OK;
 }
 
-int kdip_debug_conv3_timing(void* dev_buf) {      // (either generation's timing build accepts the buffer)
-  const int r4 = conv4_debug_timing(dev_buf), r3 = conv3_debug_timing(dev_buf);
-  return (r3 && r4) ? r3 : KDIP_OK;
-}
+int kdip_debug_conv3_timing(void* dev_buf) { return conv3_debug_timing(dev_buf); }
 int kdip_debug_gn_fold(int on) { unet_debug_gn_fold(on); return KDIP_OK; }
-int kdip_debug_conv_generation(int gen) {
-  KDIP_REQUIRE(gen == 0 || gen == 3 || gen == 4, "conv generation must be 0 (automatic), 3 or 4");
-  conv_debug_generation(gen);
-  return KDIP_OK;
-}
 
 int kdip_test_groupnorm(void* stream, int dtype, const float* x_nchw, int B, int C, int H, int W, const float* gamma_host,
                         const float* beta_host, const float* film_host, int silu, float* y_nchw, const float* dy_nchw,

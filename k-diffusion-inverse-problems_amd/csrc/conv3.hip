@@ -857,21 +857,9 @@ p.dbg = C3_TIMING ? g_c3_dbg : nullptr;
     const double in_px = p.in_ups ? px / 4 : px, res_px = p.res_ups ? px / 4 : px;
     const double bytes = in_px * cr * 2.0 * (tf == 2 ? 2 : 1) + 9.0 * cr * Cout * 2.0 + px * Cout * 2.0 + (res ? res_px * Cout * 2.0 : 0.0) +
                          (stm == 2 ? px * Cout * 2.0 : 0.0);
-    // (the profiler keeps the pointer: static storage) conv4[...]: the third-generation kernel (conv4.hip) runs this launch
-    static const char* tags4[3][3][2] = {{{"conv4", "conv4_res"}, {"conv4_s1", "conv4_s1_res"}, {"conv4_s2", "conv4_s2_res"}},
-                                         {{"conv4_gnf", "conv4_gnf_res"}, {"conv4_gnf_s1", "conv4_gnf_s1_res"}, {"conv4_gnf_s2", "conv4_gnf_s2_res"}},
-                                         {{"conv4_gnb", "conv4_gnb_res"}, {"conv4_gnb_s1", "conv4_gnb_s1_res"}, {"conv4_gnb_s2", "conv4_gnb_s2_res"}}};
-    const bool g4 = conv4_shape_ok(p, tf, stm, res != nullptr) && Cin <= conv4_tf_max_cin(tf);
-    prof_begin(st, PC_CONV3_128x128, 2.0 * px * cr * Cout * 9, bytes, (g4 ? tags4 : tags)[tf][stm][res ? 1 : 0], B, H, cr, Cout);
+    prof_begin(st, PC_CONV3_128x128, 2.0 * px * cr * Cout * 9, bytes, tags[tf][stm][res ? 1 : 0], B, H, cr, Cout);
   }
   int rc;
-  if (conv4_shape_ok(p, tf, stm, res != nullptr) && Cin <= conv4_tf_max_cin(tf)) {      // third-generation kernel (conv4.hip) where the launch fills the chip with 512-pixel tiles
-    rc = conv4_launch(p, tf, stm, res != nullptr, st);
-    prof_end(st);
-    if (rc) return rc;
-    KDIP_LAUNCH_CHECK();
-    return KDIP_OK;
-  }
 #define C3_GO(T, S, R) rc = launch3<T, S, R>(p, st)
   if (tf == 0 && stm == 0) { if (res) C3_GO(0, 0, true); else C3_GO(0, 0, false); }
   else if (tf == 0 && stm == 1) { if (res) C3_GO(0, 1, true); else C3_GO(0, 1, false); }

@@ -1,4 +1,5 @@
-// Parameter block shared by the second- (conv3.hip) and third-generation (conv4.hip) bf16 3x3 conv kernels.
+// Parameter block of the second-generation bf16 3x3 conv kernel (conv3.hip; also used by the archived ping-pong variant,
+// tools/experiments/conv4/).
 #pragma once
 #include "common.h"
 
@@ -72,11 +73,5 @@ __device__ __forceinline__ float4 c3_fold_coef_bwd(const Conv3Params& p, int b, 
   return make_float4(p.fold_coef[i * 2], p.fold_coef[i * 2 + 1], k0, k1);
 }
 #endif
-
-// conv4.hip: third-generation kernel (one 8-wave block per CU, 16 x 32-pixel x 128-channel tiles, two wave groups in ping-pong).
-// `p` is the block conv3_forward built (tile counts are recomputed for the 16-row tiles); returns KDIP_OK after the launch.
-bool conv4_shape_ok(const Conv3Params& p, int tf, int stm, bool res);
-int conv4_tf_max_cin(int tf);
-int conv4_launch(const Conv3Params& p, int tf, int stm, bool res, hipStream_t st);
 
 }  // namespace kdip

@@ -58,8 +58,6 @@ struct Conv3Fuse {
   const void* st_x = nullptr; long st_ldx = 0;
   const float* st_coef = nullptr; const float* st_mr = nullptr;
 };
-void conv_debug_generation(int gen);   // test / A-B aid: 0 automatic, 3 / 4 force the second- (conv3.hip) / third-generation (conv4.hip) kernel where the shape allows
-int conv4_debug_timing(void* buf);   // -DC4_TIMING=1 builds: [grid][8 waves][160] uint64 shader-clock stamps of each block's first tile (4 per phase)
 int conv3_debug_timing(void* buf);   // -DC3_TIMING=1 builds: [grid][8] uint64 per-block phase stamps of every later conv3 launch
 int conv3_tf_max_cin(int tf);          // most input channels the staging-transform table of mode tf holds
 bool conv3_eligible(DType dt, int ntaps, int H, int W, int Cin_pad, int Cout, long ldx, long ldy);

@@ -23,6 +23,7 @@ struct OpCtx {
   float* dctD = nullptr;           // [N][N] orthonormal DCT-II matrix
   // workspace
   int wsB = 0;
+  long ws_generation = 0;          // bumped whenever ensure_ws re-allocates the buffers below (captured hipGraphs hold their addresses)
   float2 *c0 = nullptr, *c1 = nullptr, *ctmp = nullptr;
   float* rbuf[10] = {nullptr};
   CgState cg{};

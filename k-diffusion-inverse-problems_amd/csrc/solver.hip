@@ -30,6 +30,9 @@ int OpCtx::init() {
   CK(dmalloc(this, (void**)&tw, sizeof(host)));
   KDIP_HIP_CHECK(hipMemcpy(tw, host, sizeof(host), hipMemcpyHostToDevice));
   KDIP_HIP_CHECK(hipHostMalloc((void**)&h_any, sizeof(int) * 4));
+  // allocated ONCE: captured fixed-trip graphs keep incrementing this word whatever the CG workspace does later
+  CK(dmalloc(this, (void**)&cg.unconverged, sizeof(int)));
+  KDIP_HIP_CHECK(hipMemset(cg.unconverged, 0, sizeof(int)));
   return KDIP_OK;
 }
 
@@ -51,10 +54,9 @@ int OpCtx::ensure_ws(int B) {
   CK(dmalloc(this, (void**)&cg.active, sizeof(int) * B));
   CK(dmalloc(this, (void**)&cg.iters, sizeof(int) * B));
   CK(dmalloc(this, (void**)&cg.any_active, sizeof(int)));
-  CK(dmalloc(this, (void**)&cg.unconverged, sizeof(int)));
-  KDIP_HIP_CHECK(hipMemset(cg.unconverged, 0, sizeof(int)));
   CK(dmalloc(this, (void**)&dtmp, sizeof(double) * B));
   wsB = B;
+  ++ws_generation;                 // captured graphs hold the old buffers' addresses (graphs.py re-captures)
   return KDIP_OK;
 }
 

@@ -268,7 +268,7 @@ int UNet::finalize() {
 }
 
 // --------------------------------------------------------------------------- helpers ----
-std::atomic<int> g_gn_fold{[] { const char* e = getenv("KDIP_GN_FOLD"); return e ? (atoi(e) != 0 ? 1 : 0) : 1; }()};      // 1: conv3 / conv4 compute the GroupNorm staging coefficients themselves (no gn_coef / gn_merge_stats / gn_bwd_coef launches)
+std::atomic<int> g_gn_fold{[] { const char* e = getenv("KDIP_GN_FOLD"); return e ? (atoi(e) != 0 ? 1 : 0) : 1; }()};      // 1: conv3 computes the GroupNorm staging coefficients itself (no gn_coef / gn_merge_stats / gn_bwd_coef launches)
 void unet_debug_gn_fold(int on) { g_gn_fold.store(on ? 1 : 0); }
 
 namespace {

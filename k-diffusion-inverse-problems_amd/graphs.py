@@ -13,12 +13,15 @@ What is capture-safe and what is not:
     into FIXED-TRIP mode (kdip_op_set_cg_fixed_trips): the eager warm-up call reports the iterations this sigma needs, the graph
     runs 1.5 x that + 4 iterations with no host read -- samples freeze themselves on the device when they converge, so surplus
     iterations change nothing --, and a sticky device counter records replays whose last residual check still found an active
-    sample (`cg_unconverged()`, read once per sampler run).
+    sample.  With `cg_check="each"` (default) the wrapper reads that counter after every fixed-trip replay (one stream
+    synchronisation per CG call instead of one every second iteration); a replay that was not converged is warned about, redone
+    eagerly with the adaptive solver -- the caller never receives a truncated solve -- and its graph is re-captured with twice the
+    trips.  `cg_check="deferred"` leaves the polling to the caller (`cg_unconverged()`, e.g. once per sampler run).
 
-Captured graphs hold raw pointers into the UNet handle's workspace arenas and to the denoiser's measurement tensors.  The handle
-regrows (frees + re-allocates) its arenas when a call at a new batch shape does not fit, so every graph records the handle's
-`workspace_generation()` and the measurement tensors' identities; when either changes all graphs are dropped and re-captured on
-their next use (`invalidations` counts this).
+Captured graphs hold raw pointers into the UNet handle's workspace arenas, the operator's solver workspace, the fused call's
+workspace / timestep vector and the denoiser's measurement tensors.  The handles regrow (free + re-allocate) their buffers when a
+call at a new batch shape does not fit, so every graph records the UNet's and the operator's `workspace_generation()` and the
+tensors' identities; when any of them changes all graphs are dropped and re-captured on their next use (`invalidations`).
 
 `GraphedDenoiser(den)` is a drop-in for the ConditionDenoiser it wraps (`model(x, sigma)` of the samplers)."""
 import torch
@@ -27,12 +30,15 @@ from .external import sigma_host
 
 
 class GraphedDenoiser:
-    def __init__(self, den, enabled=True, capture_cg=True, cg_margin=1.5):
+    def __init__(self, den, enabled=True, capture_cg=True, cg_margin=1.5, cg_check="each"):
+        assert cg_check in ("each", "deferred")
         self.den = den
         self.enabled = enabled
         self.capture_cg = capture_cg   # capture the CG branch too, as fixed-trip solves (trips = margin * iterations of the warm-up + 4)
         self.cg_margin = cg_margin
+        self.cg_check = cg_check       # "each": poll the unconverged counter after every fixed-trip replay, redo + re-capture on a miss
         self.cg_trips = {}
+        self.cg_redone = 0             # fixed-trip replays that were not converged and were redone eagerly
         self._graphs = {}          # (sigma, shape) -> (graph, static_x, static_out)
         self.replays = 0
         self.eager_calls = 0
@@ -48,9 +54,11 @@ class GraphedDenoiser:
         den = self.den
         model = getattr(den, "inner_model", None)
         gen = model.workspace_generation() if hasattr(model, "workspace_generation") else 0
-        meas = tuple((t.data_ptr(), tuple(t.shape)) for t in (getattr(den, n, None) for n in ("y", "y_flatten", "_y1", "_yf1"))
-                     if isinstance(t, torch.Tensor))
-        return (gen, meas)
+        op = getattr(den, "operator", None)
+        opgen = op.workspace_generation() if hasattr(op, "workspace_generation") else 0        # solver buffers (CG vectors, FFT scratch)
+        meas = tuple((t.data_ptr(), tuple(t.shape)) for t in (getattr(den, n, None) for n in ("y", "y_flatten", "_y1", "_yf1", "_fused_ws", "_fused_t"))
+                     if isinstance(t, torch.Tensor))                                                # + the fused call's workspace / timestep vector
+        return (gen, opgen, meas)
 
     def _validate(self):
         """Drop every captured graph when the handle re-allocated its arenas (a call at a larger batch shape, eager or captured,
@@ -123,6 +131,32 @@ class GraphedDenoiser:
         sx.copy_(x)
         g.replay()
         self.replays += 1
+        if key in self.cg_trips and self.cg_check == "each" and self.cg_unconverged() > 0:
+            # the fixed trip count taken from the warm-up input was too small for THIS input: the reference iterates to tolerance or
+            # maxiter and warns (condition.py:343-347), so do the same -- adaptive solve now, more trips for the next replay
+            from warnings import warn
+            warn(f"fixed-trip CG graph at sigma={s:.4g} ({self.cg_trips[key]} iterations) left a sample unconverged: call redone eagerly, graph re-captured")
+            out = self.den(x, sigma)
+            self.cg_redone += 1
+            self.eager_calls += 1
+            self._recapture_cg(key, self.cg_trips[key] * 2)
+            return out
         return so.clone()
+
+    def _recapture_cg(self, key, trips):
+        g_old, sx, so_old = self._graphs.pop(key)
+        op = self.den.operator
+        ssig = sx.new_full([sx.shape[0]], float(key[0]))
+        ssig._kdip_host_value = float(key[0])
+        op.set_cg_fixed_trips(trips)
+        self.cg_trips[key] = trips
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                so = self.den(sx, ssig)
+        finally:
+            op.set_cg_fixed_trips(0)
+        op.cg_unconverged()            # (the capture pass itself does not run kernels; clear anything the eager redo left)
+        self._graphs[key] = (g, sx, so)
 
     forward = __call__

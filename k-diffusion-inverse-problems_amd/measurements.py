@@ -132,6 +132,10 @@ class LinearOperator(ABC):
         L.check(self.lib.kdip_op_set_cg_fixed_trips(self._h, int(trips)))
         self._cg_fixed_trips = int(trips)
 
+    def workspace_generation(self):
+        """Bumped whenever the operator context re-allocates its solver workspace (captured hipGraphs hold the old buffers)."""
+        return int(self.lib.kdip_op_workspace_generation(self._h))
+
     def cg_unconverged(self):
         """Number of fixed-trip CG solves since the last query that stopped with an unconverged sample (sticky device counter, read
         and cleared; synchronises the stream)."""

@@ -650,3 +650,94 @@ def test_hipgraph_cg_branch_fixed_trips(gold, tiny):
     assert gd.cg_unconverged() == 0
     for x, o in zip(xs, outs):
         assert float((o - den(x, lo)).abs().max()) < 1e-4
+
+
+def test_graph_redoes_unconverged_fixed_trip_replay(gold, tiny):
+    """a replay whose captured trip count is too small for its input must not be returned silently.  The graph is
+    captured with a deliberately tiny margin (cg_margin 0 -> 4 trips); the wrapper polls the sticky counter after the replay,
+    warns, redoes the call with the adaptive solver (result = eager) and re-captures the key with twice the trips."""
+    import warnings
+    import kdip_amd.condition as kc
+    from kdip_amd.graphs import GraphedDenoiser
+    models, D, sd, cfg = tiny
+    hop, oop, (y, yf), x0 = make_ops("gaussian_blur", gold)
+    den = kc.ConditionOpenAIDenoiser(inner_model=models["f32"], diffusion=D, x0_cov_type="convert", recon_mse=None, operator=hop,
+                                     measurement=(y.cuda(), yf.cuda()), guidance="I", device="cuda")
+    gd = GraphedDenoiser(den, cg_margin=0.0)
+    x = (x0 + 0.12 * torch.randn(1, 3, 64, 64, generator=torch.Generator().manual_seed(29))).cuda()
+    lo = torch.tensor([0.12], device="cuda")
+    ref = den(x, lo)
+    need = max(hop.cg_iters)
+    assert need > 8, need                      # (otherwise 4 trips would be enough and the test would be vacuous)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = gd(x, lo)
+    assert any("unconverged" in str(m.message) for m in w)
+    assert gd.cg_redone == 1 and list(gd.cg_trips.values()) == [8]
+    assert float((out - ref).abs().max()) < 1e-4
+    assert gd.cg_unconverged() == 0            # nothing pending after the redo
+
+
+def test_second_vjp_after_fused_call_uses_exported_layout(gold, tiny):
+    """x0_raw of a fused Type-I call is found through kdip_guided_ws_layout (no hard-coded slice), so a second
+    VJP right after it on the same denoiser -- what tmpd / STSL do -- equals the stepwise path's."""
+    import ctypes as C
+    import kdip_amd._lib as L
+    import kdip_amd.condition as kc
+    models, D, sd, cfg = tiny
+    hop, oop, (y, yf), x0 = make_ops("gaussian_blur", gold)
+    mk = lambda: kc.ConditionOpenAIDenoiser(inner_model=models["f32"], diffusion=D, x0_cov_type="convert", recon_mse=None, operator=hop,
+                                            measurement=(y.cuda(), yf.cuda()), guidance="I", device="cuda")
+    off = (C.c_long * L.GWS_COUNT)()
+    L.check(L.load().kdip_guided_ws_layout(2, 64, off, L.GWS_COUNT))
+    n3 = 3 * 2 * 64 * 64
+    assert list(off) == sorted(off) and off[L.GWS_X0_RAW] - off[L.GWS_X0_MEAN] == n3 and off[L.GWS_SCORE] + n3 <= L.load().kdip_guided_ws_floats(2, 64)
+    with pytest.raises(L.KdipError):
+        L.check(L.load().kdip_guided_ws_layout(2, 64, off, L.GWS_COUNT - 1))
+    x = (x0 + 1.5 * torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(31))).cuda()
+    s = torch.full((2,), 1.5, device="cuda")
+    gh = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(32)).cuda()
+    fused, step = mk(), mk()
+    step.fused_call = False
+    hf, hs = fused(x, s), step(x, s)
+    assert float((hf - hs).abs().max()) < 2e-5
+    v1, v2 = fused._vjp_x0(gh), step._vjp_x0(gh)                     # the second VJP (all-ones for tmpd, Hutchinson probes for STSL)
+    assert float((v1 - v2).abs().max()) < 2e-5 * max(1.0, float(v2.abs().max()))
+    # tmpd / stsl denoisers on the same UNet handle right after a fused call: finite, and equal to a fresh denoiser's answer
+    for guidance, cov, kw in (("I", "tmpd", {}), ("stsl", "dps", dict(zeta=1.0, eta=0.5, num_hutchinson_samples=1))):
+        a = kc.ConditionOpenAIDenoiser(inner_model=models["f32"], diffusion=D, x0_cov_type=cov, recon_mse=None, operator=hop,
+                                       measurement=(y.cuda(), yf.cuda()), guidance=guidance, device="cuda", **kw)
+        fused(x, s)
+        torch.manual_seed(5); o1 = a(x, s)
+        torch.manual_seed(5); o2 = a(x, s)
+        assert torch.isfinite(o1).all() and float((o1 - o2).abs().max()) < 1e-4
+    # a wrong spatial size is refused before any workspace is sized from it
+    with pytest.raises(ValueError):
+        fused(torch.zeros(1, 3, 32, 32, device="cuda"), torch.tensor([1.5], device="cuda"))
+
+
+def test_custom_mat_solver_is_honoured_by_type_I(gold, tiny):
+    """a solver registered through the public register_mat_solver surface (condition/condition.py:307-314) must be the
+    one Type-I uses -- the fused entry point is only taken for the library's own solvers."""
+    import kdip_amd.condition as kc
+    models, D, sd, cfg = tiny
+    hop, oop, (y, yf), x0 = make_ops("gaussian_blur", gold)
+    calls = []
+    builtin = kc.__MAT_SOLVER__["gaussian_blur"]
+
+    @kc.register_mat_solver("gaussian_blur")
+    def half_mat(operator, y_, x0_mean, theta0_var, ortho_tf=None):
+        calls.append(1)
+        return 0.5 * builtin(operator, y_, x0_mean, theta0_var, ortho_tf)
+    try:
+        den = kc.ConditionOpenAIDenoiser(inner_model=models["f32"], diffusion=D, x0_cov_type="analytic", recon_mse=synthetic_recon_mse(),
+                                         operator=hop, measurement=(y.cuda(), yf.cuda()), guidance="I", device="cuda")
+        x = (x0 + 1.5 * torch.randn(1, 3, 64, 64, generator=torch.Generator().manual_seed(33))).cuda()
+        s = torch.tensor([1.5], device="cuda")
+        out = den(x, s)
+        assert calls, "the registered solver was bypassed"
+    finally:
+        kc.__MAT_SOLVER__["gaussian_blur"] = builtin
+    ref = kc.ConditionOpenAIDenoiser(inner_model=models["f32"], diffusion=D, x0_cov_type="analytic", recon_mse=synthetic_recon_mse(),
+                                     operator=hop, measurement=(y.cuda(), yf.cuda()), guidance="I", device="cuda")(x, s)
+    assert float((out - ref).abs().max()) > 1e-4          # half the likelihood score: a different estimate
