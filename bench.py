@@ -263,12 +263,14 @@ def main():
         env.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        x = run_all(parts, steps, chain)
-        hat = env.gather(x)
+        x = run_all(parts, steps, chain)                       # (ends with a device synchronisation)
+        t1 = time.perf_counter()
+        hat = env.gather(x)                                    # the path's one collective: all_gather of the results (RCCL over xGMI)
         torch.cuda.synchronize()
+        timed_run.gather_ms = (time.perf_counter() - t1) * 1e3
         env.barrier()
         elapsed = env.max_over_ranks(time.perf_counter() - t0)
-        assert torch.isfinite(hat).all()
+        assert torch.isfinite(hat).all() and hat.shape[0] == env.world_size * x.shape[0]
         return elapsed
 
     full_run = args.steps % 100 == 0 and args.steps > 0
@@ -283,6 +285,8 @@ def main():
         elapsed = timed_run(parts, idx, full_run, args.warmup)
     den, x0 = parts[0]["den"], parts[0]["x0"]             # the roofline leg profiles part 0 alone
 
+    gather_ms = env.max_over_ranks(getattr(timed_run, "gather_ms", 0.0))
+    topo = env.topology()                                      # (after the timed region)
     ms_per_step = elapsed / args.steps * 1e3
     images_per_s = env.world_size * B / (ms_per_step * 100 / 1e3)
     out = {
@@ -297,6 +301,10 @@ def main():
                    "timed_steps": "full 100-step sampler run" if full_run else "two-call Heun steps spread evenly over steps 0..98 of the 100-step schedule (the single-call final step is never in a subset)",
                    "parallelism": f"dp{env.world_size} (independent images, one all_gather at the end)"},
         "achieved_tflops_whole_step": round(2 * B * FWD_VJP_GFLOP_PER_IMAGE_CALL / ms_per_step, 2),
+        # multi-GPU evidence (k_diffusion/evaluation.py:53-63): N ranks on N distinct devices, the collective's backend, and the
+        # time of the final all_gather (inside the timed region; max over ranks)
+        "ranks": topo["ranks"], "distinct_devices": topo["distinct_devices"], "backend": topo["backend"], "devices": topo["devices"],
+        "gather_ms": round(gather_ms, 3), "gather_bytes_per_rank": B * 3 * S * S * 4,
     }
     pw = sampler.summary() if sampler else None
     if pw:

@@ -46,11 +46,17 @@ struct Layer {
 
 struct Arena {
   char* base = nullptr; size_t cap = 0, off = 0, peak = 0;
+  bool overflow = false;            // a real pass asked for more than the plan reserved: the pass is aborted by run() / vjp()
   void* alloc(size_t bytes) {
     size_t a = (off + 255) & ~(size_t)255;
     off = a + bytes;
     if (off > peak) peak = off;
-    return base ? (void*)(base + a) : (void*)(uintptr_t)(a + 4096);   // dry run: fake non-null address
+    if (!base) return (void*)(uintptr_t)(a + 4096);                   // dry run: fake non-null address
+    if (off > cap) {                // never hand out memory past the arena: park the request at the start (garbage results, no
+      overflow = true;              // out-of-bounds write as long as the request itself fits) -- the caller checks `overflow`
+      return (void*)base;
+    }
+    return (void*)(base + a);
   }
   void reset() { off = 0; }
 };

@@ -305,7 +305,10 @@ int gn_forward(Ctx& c, const void* x, long ldx, int B, long HW, const GnW& g, co
       if (C2 <= 0 || !gn_merge_eligible(C1, C2)) continue;
       auto hi = c.u->fused_stats.find(std::make_pair((const void*)((const char*)x + c.es * C1), C2));
       if (hi == c.u->fused_stats.end()) continue;
-      if (do_fold) { stats = lo->second; stats2 = hi->second; mC1 = C1; break; }      // merged by the conv while it loads its table
+      if (do_fold) {      // merged by the conv while it loads its table; the merged sums are still reserved, so that the workspace
+        (void)new_sums(c, B);   // plan of a batch does not depend on the state of the fold switch when it was made (kdip_debug_gn_fold)
+        stats = lo->second; stats2 = hi->second; mC1 = C1; break;
+      }
       stats = new_sums(c, B);
       RUN(gn_merge_stats(c.st, lo->second, C1, hi->second, C2, B, stats));
       break;
@@ -932,9 +935,9 @@ int UNet::run(hipStream_t st, const float* x_nchw, const float* t, int B, float 
   CK(ensure_workspace(B));
   have_stash = false;
   CK(forward_impl(st, x_nchw, t, B, in_scale, out_nchw, cov_nchw, feat_nchw));
-  if (persist.peak > persist.cap || scratch.peak > scratch.cap || zeros.peak > zeros.cap)
-    return set_error(KDIP_ERR_STATE, "internal: workspace arena overflow (persist %zu/%zu, scratch %zu/%zu)", persist.peak,
-                     persist.cap, scratch.peak, scratch.cap);
+  if (persist.overflow || scratch.overflow || zeros.overflow || persist.peak > persist.cap || scratch.peak > scratch.cap || zeros.peak > zeros.cap)
+    return set_error(KDIP_ERR_STATE, "internal: workspace arena overflow (persist %zu/%zu, scratch %zu/%zu, zeros %zu/%zu)", persist.peak,
+                     persist.cap, scratch.peak, scratch.cap, zeros.peak, zeros.cap);
   last_B = B;
   have_stash = true;
   (void)save;
@@ -945,7 +948,7 @@ int UNet::vjp(hipStream_t st, const float* cot_nchw, float* gx_nchw) {
   if (!have_stash) return set_error(KDIP_ERR_STATE, "unet_vjp without a preceding unet_forward");
   size_t mark = persist.off;
   int rc = vjp_impl(st, cot_nchw, gx_nchw);
-  if (!rc && (persist.peak > persist.cap || scratch.peak > scratch.cap || zeros.peak > zeros.cap))
+  if (!rc && (persist.overflow || scratch.overflow || zeros.overflow || persist.peak > persist.cap || scratch.peak > scratch.cap || zeros.peak > zeros.cap))
     rc = set_error(KDIP_ERR_STATE, "internal: workspace arena overflow in the VJP");
   persist.off = mark;   // the stash stays valid: the VJP may be called again (tmpd / STSL style)
   return rc;

@@ -54,6 +54,36 @@ class DistEnv:
         if self.world_size > 1:
             dist.barrier()
 
+    def device_identity(self):
+        """What physical device this rank computes on: (hostname, PCI bus id | device UUID | index) -- distinct across the ranks
+        of one node iff every rank has its own GPU."""
+        import socket
+        ident = f"cpu:{os.getpid()}"
+        if self.device.type == "cuda":
+            p = torch.cuda.get_device_properties(self.device)
+            ident = None
+            for attr in ("pci_bus_id", "uuid"):
+                v = getattr(p, attr, None)
+                if v is not None and str(v) not in ("", "0"):
+                    ident = f"{attr}:{v}" + (f".{getattr(p, 'pci_device_id', '')}" if attr == "pci_bus_id" else "")
+                    break
+            if ident is None:
+                ident = f"index:{self.device.index}"
+        return (socket.gethostname(), ident)
+
+    def topology(self):
+        """{"ranks", "distinct_devices", "backend", "devices"}: every rank's device identity gathered to all ranks (one small
+        all_gather_object, outside any timed region) -- evidence that an N-rank run really used N devices over RCCL."""
+        me = self.device_identity()
+        if self.world_size == 1:
+            ids = [me]
+            backend = "none (single process)"
+        else:
+            ids = [None] * self.world_size
+            dist.all_gather_object(ids, me)
+            backend = dist.get_backend()
+        return {"ranks": self.world_size, "distinct_devices": len(set(ids)), "backend": backend, "devices": [f"{h}/{d}" for h, d in ids]}
+
     def max_over_ranks(self, value):
         if self.world_size == 1:
             return value

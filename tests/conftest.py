@@ -11,15 +11,19 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "gpu2: needs two MI355X on one node (RCCL); skipped elsewhere (run with -m gpu2)")
 
 
 def pytest_collection_modifyitems(config, items):
     import torch
-    if torch.cuda.is_available():
-        return
+    ngpu = torch.cuda.device_count() if torch.cuda.is_available() else 0
     skip = pytest.mark.skip(reason="no GPU visible")
+    skip2 = pytest.mark.skip(reason="needs 2 GPUs on this node (%d visible)" % ngpu)
     for item in items:
-        if "gpu" in item.keywords:
+        if "gpu2" in item.keywords:
+            if ngpu < 2:
+                item.add_marker(skip2)
+        elif "gpu" in item.keywords and ngpu < 1:
             item.add_marker(skip)
 
 

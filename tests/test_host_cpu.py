@@ -157,6 +157,8 @@ assert out.shape == (6, 3, 2, 2), out.shape
 assert out[:, 0, 0, 0].tolist() == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0], out[:, 0, 0, 0]
 t = env.max_over_ranks(float(env.rank + 1))
 assert t == 2.0
+topo = env.topology()
+assert topo["ranks"] == 2 and topo["distinct_devices"] == 2 and topo["backend"] == "gloo" and len(topo["devices"]) == 2, topo
 env.barrier()
 print("rank", env.rank, "ok")
 '''
