@@ -129,6 +129,70 @@ def test_imagenet_motion_typeI_analytic_fullsize(sigma_v):
     assert torch.isfinite(hat2).all() and p > 25.0      # measured 30.0 dB (sigma 1.5: clamp flips on saturated random-weight outputs) / 66.1 dB (sigma 0.12)
 
 
+FULLSIZE = [
+    # BASELINE configs[0], [2], [4] (configs[1] and [3] have their own tests above): (id, operator, guidance, cov, extra, v2 basis, low sigma)
+    ("cfg0_inpaint_dps", "inpainting", "dps", "dps", dict(zeta=1.0), None, 0.12),                 # condition.py:140-148, measurements.py:202-244
+    ("cfg2_sr4_typeII_pgdm", "super_resolution", "II", "pgdm", {}, None, 0.12),                   # condition.py:176-183, measurements.py:86-122
+    ("cfg4_gauss_v2_dwt_autoI", "gaussian_blur", "autoI", None, {}, "dwt", 0.5),                  # condition.py:287-300,133-138; CG in the DWT basis below sigma 1
+]
+
+
+@pytest.mark.parametrize("cid,opn,guid,cov,extra,ortho,sig_lo", FULLSIZE)
+def test_baseline_configs_fullsize_vs_oracle(cid, opn, guid, cov, extra, ortho, sig_lo):
+    """One high-sigma and one low-sigma guided call of BASELINE configs[0] / [2] / [4] at 256 x 256 (FFHQ architecture, batch 2)
+    against the CPU oracle on the same inputs: f32 and bf16x3 within 2e-3 max-abs (the f32-mode bound of the guided-call goldens),
+    bf16 as PSNR(hip, oracle), printed and bounded.  configs[4] rides on the DWT layout restated from pywt's documentation
+    (parity unpinned at that third-party boundary, oracle/transforms.py)."""
+    import kdip_amd.unet as ku
+    import kdip_amd.condition as kc
+    import kdip_amd.external as ke
+    from oracle import condition as ocond
+    B = 2
+    m, sd, ocfg, hop, oop, meas, x0 = _setup("FFHQ", opn, "f32", B=B, out_cov=ortho is not None)
+    D = ku.GaussianDiffusionTables()
+    measd = (meas[0].cuda(), meas[1].cuda())
+
+    def hip_den(model):
+        if ortho is None:
+            return kc.ConditionOpenAIDenoiser(inner_model=model, diffusion=D, x0_cov_type=cov, recon_mse=None, operator=hop, measurement=measd,
+                                              guidance=guid, zeta=extra.get("zeta"), device="cuda").eval()
+        return kc.ConditionOpenAIDenoiserV2(ke.OpenAIDenoiserV2(model, D, ortho_tf_type=ortho), operator=hop, measurement=measd, guidance=guid,
+                                            mle_sigma_thres=1.0, device="cuda", ortho_tf_type=ortho).eval()
+    outs = {}
+    for dtype in ("f32", "bf16x3", "bf16"):
+        if dtype != "f32":
+            del m
+            torch.cuda.empty_cache()
+            m = ku.UNetModel(dtype=dtype, **ku.FFHQ_CONFIG); m.load_state_dict(sd)
+        den = hip_den(m)
+        for sigma_v in (1.5, sig_lo):
+            x = x0 + sigma_v * torch.randn(B, 3, 256, 256, generator=torch.Generator().manual_seed(11))
+            hat = den(x.cuda(), torch.full((B,), sigma_v, device="cuda")).cpu()
+            raw = den._stash[0].cpu() if (ortho is None and guid != "II") else None      # V1 paths with a VJP: x0_raw for the clamp mask
+            outs[(dtype, sigma_v)] = (x, hat, raw)
+    for sigma_v in (1.5, sig_lo):
+        x, hat, raw = outs[("f32", sigma_v)]
+        if ortho is None:
+            oden = ocond.GuidedDenoiser(sd, ocfg, oop, meas, guid, x0_cov_type=cov, zeta=extra.get("zeta"))
+        else:
+            oden = ocond.GuidedDenoiser(sd, ocfg, oop, meas, guid, mle_sigma_thres=1.0, v2=True, ortho_tf_type=ortho)
+        flips = 0
+        if raw is not None:      # borderline |x0_raw| = 1 pixels have two correct answers (see test_imagenet_motion_typeI_analytic_fullsize)
+            oden.clamp_mask_override = raw.abs() <= 1
+        ref = oden(x, torch.full((B,), sigma_v))
+        if raw is not None:
+            fl = (oden.last_x0_raw.abs() <= 1) != oden.clamp_mask_override
+            flips = int(fl.sum())
+            assert flips <= 4 and (flips == 0 or float((oden.last_x0_raw[fl].abs() - 1).abs().max()) < 1e-4)
+        e32 = float((hat - ref).abs().max())
+        ex3 = float((outs[("bf16x3", sigma_v)][1] - ref).abs().max())
+        p16 = psnr_db(outs[("bf16", sigma_v)][1], ref)
+        iters = f", oracle CG iterations {oden.cg_stats.get('iters')}" if oden.cg_stats.get("iters") is not None else ""
+        print(f"\n{cid} sigma={sigma_v} B={B} ({flips} borderline clamp pixels{iters}): f32 max-abs {e32:.2e}; bf16x3 max-abs {ex3:.2e}; bf16 PSNR(hip, oracle) {p16:.1f} dB")
+        assert e32 < 2e-3 and ex3 < 2e-3, (cid, sigma_v, e32, ex3)
+        assert p16 > 25.0, (cid, sigma_v, p16)
+
+
 E2E = [
     # (operator, guidance, covariance, extra)  -- BASELINE configs[0..3] guidance per operator
     ("gaussian_blur", "I", "convert", {}),
@@ -143,8 +207,9 @@ def test_e2e_bf16_vs_f32_psnr(opn, guid, cov, extra):
     """End-to-end fidelity of the benchmarked arithmetic: full 20-step Euler and 20-step Heun `--ode` runs at 256x256
     (FFHQ architecture, batch 2, random-init weights), bf16 HIP vs f32 HIP from the same x_T.  Printed: PSNR of each
     result against the ground truth, |PSNR_bf16 - PSNR_f32| (the north_star quantity), and PSNR(bf16, f32) between the two
-    results.  The f32 mode is the one pinned to the reference at 1e-3 dB (test_parity_gpu.py); what bf16 holds is asserted
-    here as a stated bound and recorded in gpurun_out/e2e_bf16_vs_f32.jsonl."""
+    results.  The f32 mode is the one pinned to the reference at 1e-3 dB (test_parity_gpu.py); the split-precision mode (bf16x3) must
+    stay within that same 1e-3 dB of it over the whole run; what bf16 holds is asserted as a stated bound.
+    Recorded in gpurun_out/e2e_bf16_vs_f32.jsonl."""
     import json, os
     import kdip_amd.unet as ku
     import kdip_amd.condition as kc
@@ -158,26 +223,31 @@ def test_e2e_bf16_vs_f32_psnr(opn, guid, cov, extra):
     xT = torch.randn(B, 3, 256, 256, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)) * 80
     sig = ks.get_sigmas_karras(20, 0.01, 80, rho=7.0, device="cuda")
     outs = {}
-    for dtype in ("f32", "bf16"):
-        if dtype == "bf16":
+    for dtype in ("f32", "bf16x3", "bf16"):
+        if dtype != "f32":
             del m
             torch.cuda.empty_cache()
-            m = ku.UNetModel(dtype="bf16", **ku.FFHQ_CONFIG); m.load_state_dict(sd)
+            m = ku.UNetModel(dtype=dtype, **ku.FFHQ_CONFIG); m.load_state_dict(sd)
         den = kc.ConditionOpenAIDenoiser(inner_model=m, diffusion=D, x0_cov_type=cov, recon_mse=None, operator=hop,
                                          measurement=measd, guidance=guid, zeta=extra.get("zeta"), device="cuda")
         for sampler, fn in (("euler", ks.sample_euler), ("heun", ks.sample_heun)):
             outs[(dtype, sampler)] = fn(den, xT.clone(), sig, disable=True).cpu()
     rec = {"operator": opn, "guidance": guid, "cov": cov, "steps": 20, "batch": B}
     for sampler in ("euler", "heun"):
-        a, b = outs[("f32", sampler)], outs[("bf16", sampler)]
-        assert torch.isfinite(a).all() and torch.isfinite(b).all()
+        a, b, c3 = outs[("f32", sampler)], outs[("bf16", sampler)], outs[("bf16x3", sampler)]
+        assert torch.isfinite(a).all() and torch.isfinite(b).all() and torch.isfinite(c3).all()
         pa = [float(psnr(a[i:i + 1], x0[i:i + 1])) for i in range(B)]
         pb = [float(psnr(b[i:i + 1], x0[i:i + 1])) for i in range(B)]
+        pc = [float(psnr(c3[i:i + 1], x0[i:i + 1])) for i in range(B)]
         dp = max(abs(u - v) for u, v in zip(pa, pb))
-        cross = psnr_db(b, a)
-        rec[sampler] = {"psnr_f32_vs_gt": pa, "psnr_bf16_vs_gt": pb, "max_abs_dpsnr_db": dp, "psnr_bf16_vs_f32_db": cross}
-        print(f"\ne2e {opn} {guid}/{cov} {sampler} 20 steps: PSNR vs GT f32 {pa} bf16 {pb}  |dPSNR| {dp:.4f} dB  PSNR(bf16,f32) {cross:.1f} dB")
-        assert dp < 0.5, (opn, sampler, dp)            # stated bf16 bound (random-init weights): half a dB end to end
+        dp3 = max(abs(u - v) for u, v in zip(pa, pc))
+        cross, cross3 = psnr_db(b, a), psnr_db(c3, a)
+        rec[sampler] = {"psnr_f32_vs_gt": pa, "psnr_bf16_vs_gt": pb, "psnr_bf16x3_vs_gt": pc, "max_abs_dpsnr_db": dp, "max_abs_dpsnr_bf16x3_db": dp3,
+                        "psnr_bf16_vs_f32_db": cross, "psnr_bf16x3_vs_f32_db": cross3}
+        print(f"\ne2e {opn} {guid}/{cov} {sampler} 20 steps: PSNR vs GT f32 {pa} bf16 {pb} bf16x3 {pc}  |dPSNR| bf16 {dp:.4f} dB, bf16x3 {dp3:.2e} dB  "
+              f"PSNR(bf16,f32) {cross:.1f} dB, PSNR(bf16x3,f32) {cross3:.1f} dB")
+        assert dp < 0.05, (opn, sampler, dp)           # bf16 bound: 3 x the largest measured deviation (0.012 dB, random-init weights)
+        assert dp3 < 1e-3, (opn, sampler, dp3)         # split-precision mode: the north_star tolerance, end to end at full size
     os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
     with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "e2e_bf16_vs_f32.jsonl"), "a") as f:
         f.write(json.dumps(rec) + "\n")

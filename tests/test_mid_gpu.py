@@ -1,0 +1,111 @@
+"""GPU: the MID-SIZE reference capture (tests/golden/unet_mid.npz, oracle/make_golden_mid.py): model_channels 128, 64 x 64,
+channel_mult (1, 2), batch 12 -- large enough that the production bf16 path routes its 64 x 64 convs through csrc/conv3.hip
+(GroupNorm + SiLU staging `gnf`, fused forward / backward statistics `s1` / `s2`, GroupNorm-backward staging `gnb`, coefficient
+fold), so those kernels are compared with REFERENCE output (guided_diffusion/unet.py:636-668 forward, its autograd input-VJP, and
+condition/condition.py:83-131 guided calls), not only with the oracle.  f32 and bf16x3 run the same fixture at the f32 bounds."""
+import csv
+import ctypes as C
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import psnr_db
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope="module")
+def mid():
+    import kdip_amd.unet as ku
+    from oracle import unet as ounet
+    from oracle.make_golden_mid import MID
+    cfg = ounet.UNetConfig(**MID)
+    sd = ounet.init_state_dict(cfg, seed=0)
+    models = {}
+    for dt in ("f32", "bf16x3", "bf16"):
+        m = ku.UNetModel(dtype=dt, **MID)
+        m.load_state_dict(sd)
+        models[dt] = m
+    return models, ku.GaussianDiffusionTables()
+
+
+def _profiled_tags(fn):
+    """conv launch tags (library HIP-event profiler) of the kernels `fn` enqueues"""
+    import kdip_amd._lib as L
+    lib = L.load()
+    L.check(lib.kdip_profile_enable(1))
+    try:
+        out = fn()
+        torch.cuda.synchronize()
+        dump = os.path.join(tempfile.gettempdir(), f"kdip_mid_{os.getpid()}.csv")
+        L.check(lib.kdip_profile_dump(dump.encode()))
+    finally:
+        L.check(lib.kdip_profile_enable(0))
+    tags = {r["tag"] for r in csv.DictReader(open(dump)) if r["class"].startswith("conv")}
+    return out, tags
+
+
+# max |err| / max |ref| of the UNet output and of the input-VJP per arithmetic mode: f32 / bf16x3 the exact-mode bound, bf16 3 x measured
+UNET_BOUNDS = {"f32": (1e-4, 1e-4), "bf16x3": (1e-4, 1e-4), "bf16": (None, None)}
+
+
+def test_unet_mid_forward_vjp_vs_reference(gold, mid):
+    from oracle.make_golden_mid import inputs
+    models, D = mid
+    g = gold("unet_mid")
+    x, t, cot = inputs()
+    for dt, m in models.items():
+        def run():
+            out = m.forward_raw(x.cuda(), t.cuda())[0]
+            return out, m.vjp(cot.cuda())
+        (out, vjp), tags = _profiled_tags(run)
+        eo = float((out.cpu() - T(g["out"])).abs().max() / T(g["out"]).abs().max())
+        ev = float((vjp.cpu() - T(g["vjp"])).abs().max() / T(g["vjp"]).abs().max())
+        print(f"\nmid UNet {dt}: forward rel-max {eo:.2e}, VJP rel-max {ev:.2e}; conv tags {sorted(tags)}")
+        if dt == "bf16":     # the point of this fixture: the second-generation kernel and its fusions ran
+            assert {"conv3_gnf_s1", "conv3_gnb_s2"} <= tags or {"conv3_gnf_s1_res", "conv3_gnb_s2"} <= tags, tags
+            assert eo < 6e-2 and ev < 6e-2, (eo, ev)
+        else:
+            assert eo < UNET_BOUNDS[dt][0] and ev < UNET_BOUNDS[dt][1], (dt, eo, ev)
+
+
+@pytest.mark.parametrize("sigma_v", [1.5, 0.12])
+def test_guided_calls_mid_vs_reference(gold, mid, sigma_v):
+    """12 batch-1 reference calls (Gaussian deblur, Type-I, Convert) = ONE batch-12 call here (B independent problems)."""
+    import kdip_amd.condition as kc
+    import kdip_amd.measurements as km
+    from oracle import operators as oops
+    from oracle.make_golden_mid import guided_inputs, B
+    models, D = mid
+    g = gold("unet_mid")
+    kw = dict(in_shape=(1, 3, 64, 64), kernel_size=61, intensity=3.0, sigma_s=0.05)
+    oop = oops.get_operator("gaussian_blur", **kw)
+    hop = km.get_operator("gaussian_blur", device="cuda", **kw)
+    x0, xs = guided_inputs(sigma_v)
+    ys, yfs = [], []
+    for i in range(B):       # the measurements the fixture was generated with (same CPU noise stream per image)
+        torch.manual_seed(2 + i)
+        y, yf = oop.forward(x0[i:i + 1].clone(), flatten=True)
+        ys.append(y); yfs.append(yf)
+    meas = (torch.cat(ys).cuda(), torch.cat(yfs).cuda())
+    ref = T(g[f"hat|{sigma_v}"])
+    for dt, m in models.items():
+        den = kc.ConditionOpenAIDenoiser(inner_model=m, diffusion=D, x0_cov_type="convert", recon_mse=None, operator=hop, measurement=meas,
+                                         guidance="I", mle_sigma_thres=0.2, device="cuda").eval()
+        hat, tags = _profiled_tags(lambda: den(xs.cuda(), torch.full((B,), sigma_v, device="cuda")))
+        hat = hat.cpu()
+        err = float((hat - ref).abs().max())
+        ps = [psnr_db(hat[i], ref[i]) for i in range(B)]
+        print(f"\nmid guided call sigma={sigma_v} {dt}: max-abs {err:.2e}, PSNR(hip, reference) min {min(ps):.1f} / median {sorted(ps)[B // 2]:.1f} dB")
+        if dt == "bf16":
+            assert any(tg.startswith("conv3_gn") for tg in tags), tags
+            assert min(ps) > 30.0, ps
+        else:
+            assert err < 2e-3, (dt, err)
