@@ -142,6 +142,8 @@ struct ConvParams {
   const void* st_x; long st_ldx;  // mode 2
   const float* st_coef;           // mode 2: [B][Cout][2] (a, b)
   const float* st_mr;             // mode 2: [B][32][2] (mean, rstd)
+  const float* tf_coef; int tf_silu;   // split precision, 3x3: the input is a GroupNorm INPUT; silu?(a*x + b) with (a, b) = tf_coef[B][Cin][2] is applied while
+                                  // the patch is staged (conv zero padding applies to the transformed tensor); one image per tile only
   const unsigned* x3_amax;        // split precision: optional device word = bits of max |x| of the input's tensor family (sets the fp16 window of the A operand)
   unsigned long long* dbg;        // KDIP_TIMING builds: [grid][8] s_memrealtime stamps (start, staged, k-loop done, end, store loop done, sync 1, sync 2)
 };
@@ -401,7 +403,9 @@ __device__ __forceinline__ void epilogue_bf16_fast(const ConvParams& p, f32x16 (
 
 // SUBS = 32-channel sub-chunks staged in LDS per barrier (1 for 3x3; up to 4 for 1x1 so a barrier
 // covers 32 MFMAs per wave instead of 8).
-template <typename T, int NTAPS, int WAVES_M, int WAVES_N, int MT, int NT, int SUBS>
+// TFM 1 (split precision, 3x3 only): the staging transform of ConvParams::tf_coef is compiled in (its own instantiation: the
+// transform's registers do not fit next to the two-deep weight pipeline of the plain one)
+template <typename T, int NTAPS, int WAVES_M, int WAVES_N, int MT, int NT, int SUBS, int TFM = 0>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::value) ? (MT * NT == 4 ? KDIP_X3_OCC : 2) : (sizeof(T) == 2 && NTAPS == 9) ? (MT * NT == 4 ? KDIP_OCC : (MT * NT == 8 ? 2 : 1)) : ((sizeof(T) == 2 && NTAPS == 1 && MT * NT == 4 && SUBS == 2) ? 3 : 1)) void conv_igemm_kernel(ConvParams p) {
   constexpr bool X3 = std::is_same<T, f32x3_t>::value;     // fp32 storage, operands split into bf16 hi / lo planes on the way into LDS
   constexpr int NPA = Mma<T>::NPA, NPB = Mma<T>::NPB, NTERM = Mma<T>::NTERM;
@@ -565,7 +569,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
   const int c_begin = p.sk_splits > 1 ? (int)((long)nchunks_all * blockIdx.y / p.sk_splits) : 0;
   const int nchunks = p.sk_splits > 1 ? (int)((long)nchunks_all * (blockIdx.y + 1) / p.sk_splits) : nchunks_all;   // = c_end
   uint4 areg[MAXV];
+  constexpr bool x3_tf = X3 && TFM != 0;
+  int tf_chunk = 0;                                    // chunk the staging registers hold
   auto stage_load = [&](int c) {
+    tf_chunk = c;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       areg[i] = make_uint4(0, 0, 0, 0);
@@ -581,6 +588,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
     }
   };
   auto stage_write = [&](int buf) {
+    // staging transform: (a, b) of this thread's 4 channels of the staged chunk (thread -> channel group is the same for all its
+    // vectors: NTHREADS % VPP == 0); fetched here (L2-hot, 32 bytes) rather than with the patch loads: 8 fewer registers live
+    // across the MFMA stages
+    float4 tfk[2] = {make_float4(1.f, 0.f, 1.f, 0.f), make_float4(1.f, 0.f, 1.f, 0.f)};
+    if (x3_tf) {
+      const float4* cf = (const float4*)(p.tf_coef + ((long)img0 * p.Cin + (long)tf_chunk * KCH + (tid % VPP) * 4) * 2);
+      tfk[0] = cf[0]; tfk[1] = cf[1];
+    }
 #pragma unroll
     for (int i = 0; i < MAXV; ++i)
     {
@@ -590,6 +605,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
         if (pix < npix) {
           float f[4];
           unpack16<float>(areg[i], f);
+          if (x3_tf) {                                   // (block-uniform) GroupNorm (+ FiLM) (+ SiLU) of the staged element
+            f[0] = tfk[0].x * f[0] + tfk[0].y; f[1] = tfk[0].z * f[1] + tfk[0].w;
+            f[2] = tfk[1].x * f[2] + tfk[1].y; f[3] = tfk[1].z * f[3] + tfk[1].w;
+            if (p.tf_silu) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) f[e] = silu_fast(f[e]);
+            }
+            if (goff[i] < 0) { f[0] = f[1] = f[2] = f[3] = 0.f; }      // zero padding of the TRANSFORMED tensor
+          }
           if (x3_scaled) {                               // (block-uniform) exact power-of-two scaling
 #pragma unroll
             for (int e = 0; e < 4; ++e) f[e] *= x3_sa;
@@ -626,7 +650,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
 #pragma unroll
         for (int pl = 0; pl < NPB; ++pl) dst[ks][nt][pl] = bptr(tp, (long)c32 * KS + ks, nt)[pl * 64];
   };
-  constexpr int BD = X3 ? (NTAPS == 9 ? KDIP_X3_B_DEPTH : 1) : (MT * NT <= 2 && sizeof(T) == 2 && NTAPS == 9) ? KDIP_B_DEPTH_SMALL : KDIP_B_DEPTH;   // stages ahead
+  constexpr int BD = X3 ? ((NTAPS == 9 && !TFM) ? KDIP_X3_B_DEPTH : 1) : (MT * NT <= 2 && sizeof(T) == 2 && NTAPS == 9) ? KDIP_B_DEPTH_SMALL : KDIP_B_DEPTH;   // stages ahead
   uint4 bq[BD + 1][KS][NT][NPB];
 
   // prologue: the first two B stages are requested together with the first patch, ahead of the LDS write + barrier
@@ -1000,7 +1024,9 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
     return set_error(KDIP_ERR_UNSUPPORTED, "conv: fused GroupNorm statistics not available for this shape");
   int nblkN = cdiv(p.ntilesN * 32, BN);
   long grid = (long)p.mtiles * nblkN;
-  auto kern = conv_igemm_kernel<T, NTAPS, WAVES_M, WAVES_N, MT, NT, SUBS>;
+  constexpr bool TF_OK = std::is_same<T, f32x3_t>::value && NTAPS == 9 && SUBS == 1;
+  if (p.tf_coef && !(TF_OK && TB == 1)) return set_error(KDIP_ERR_UNSUPPORTED, "conv: fused GroupNorm staging is not available for this shape");
+  auto kern = (TF_OK && p.tf_coef) ? conv_igemm_kernel<T, NTAPS, WAVES_M, WAVES_N, MT, NT, SUBS, (TF_OK ? 1 : 0)> : conv_igemm_kernel<T, NTAPS, WAVES_M, WAVES_N, MT, NT, SUBS, 0>;
   p.dbg = (KDIP_TIMING && g_conv_dbg && NTAPS == 9 && p.H == g_dbg_H && p.cin_real == g_dbg_cin && p.Cout == g_dbg_cout &&
            p.st_mode == g_dbg_mode && grid <= 16384) ? g_conv_dbg : nullptr;
   if (g_prof_on) {
@@ -1012,7 +1038,8 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
   if (lds > 48 * 1024) {
     // raise the dynamic-LDS cap once per (instantiation, device); the attribute is per device, and launches may come from
     // several host threads (run_on_streams): an atomic device bit mask, setting the attribute twice is harmless
-    static std::atomic<unsigned long long> granted{0};
+    static std::atomic<unsigned long long> granted2[2] = {{0}, {0}};       // [plain | staging-transform instantiation]
+    std::atomic<unsigned long long>& granted = granted2[(TF_OK && p.tf_coef) ? 1 : 0];
     int dev = 0;
     KDIP_HIP_CHECK(hipGetDevice(&dev));
     const unsigned long long bit = 1ull << (dev & 63);
@@ -1129,6 +1156,9 @@ int conv_forward(hipStream_t st, DType dt, int ntaps, const void* x, long ldx, i
   p.st_mode = 0; p.st_silu = 0; p.st_sums = nullptr; p.st_x = nullptr; p.st_ldx = 0; p.st_coef = nullptr; p.st_mr = nullptr;
   p.in_ups = stt ? stt->in_ups : 0; p.res_ups = stt ? stt->res_ups : 0;
   p.x3_amax = stt ? stt->x3_amax : nullptr;
+  p.tf_coef = stt ? stt->tf_coef : nullptr; p.tf_silu = stt ? stt->tf_silu : 0;
+  KDIP_REQUIRE(!p.tf_coef || (dt == DT_F32X3 && ntaps == 9 && (long)H * W >= 128 && ((uintptr_t)p.tf_coef % 16) == 0),
+               "conv: fused GroupNorm staging needs the split-precision 3x3 kernel and one image per tile");
   p.sk_ws = sk_ws; p.sk_ws_floats = sk_ws_floats; p.sk_splits = 1;
   KDIP_REQUIRE(!(p.in_ups || p.res_ups) || (H % 2 == 0 && W % 2 == 0), "conv: fused x2 upsample needs even H, W");
   if (stt && stt->mode) {

@@ -17,7 +17,11 @@ struct ConvStats {
   // split-precision mode (DT_F32X3): device word holding the bits of max |x| of the tensor family the INPUT belongs to (the VJP's
   // cotangent), or null for inputs of O(1) scale (forward activations): sets the fp16 window of the A operand (conv.hip, Mma<f32x3_t>)
   const unsigned* x3_amax = nullptr;
+  // split-precision 3x3 convs on maps with >= 128 pixels: the input is a GroupNorm INPUT and silu?(a*x + b), (a, b) = tf_coef [B][Cin][2]
+  // (gn_coef), is applied while the patch is staged -- the activated tensor never exists in HBM (as Conv3Fuse::tf 1 does for bf16)
+  const float* tf_coef = nullptr; int tf_silu = 0;
 };
+inline bool conv_tf_eligible(DType cdt, int ntaps, int H, int W, int Cin_pad) { return cdt == DT_F32X3 && ntaps == 9 && (long)H * W >= 128 && Cin_pad % 32 == 0; }
 // true iff conv_forward can fuse statistics for an output of this shape
 inline bool conv_stats_eligible(int H, int W, int Cout) { return (long)H * W >= 128 && Cout % 128 == 0; }
 int conv_forward(hipStream_t st, DType dt, int ntaps, const void* x, long ldx, int B, int H, int W, int Cin,

@@ -398,16 +398,18 @@ int conv_f(Ctx& c, const ConvW& w, const void* x, long ldx, int B, int H, int W,
     RUN(conv3_forward(c.st, x, ldx, B, H, W, w.cin_pad, w.wf, w.bias, w.cout, y, ldy, res, ldr, &fu, w.cin));
     return KDIP_OK;
   }
-  if (tf_coef) return set_error(KDIP_ERR_STATE, "internal: fused GroupNorm staging requested for a conv the second-generation kernel cannot run");
+  if (tf_coef && !conv_tf_eligible(c.cdt(), w.ntaps, H, W, w.cin_pad))
+    return set_error(KDIP_ERR_STATE, "internal: fused GroupNorm staging requested for a conv no kernel can fuse it into");
   ConvStats stt;
   stt.in_ups = in_ups; stt.res_ups = res_ups;
+  if (tf_coef) { stt.tf_coef = tf_coef; stt.tf_silu = 1; }
   if (stats_ok) {
     stt.mode = 1;
     stt.sums = new_sums(c, B);
     c.u->fused_stats[std::make_pair((const void*)y, w.cout)] = stt.sums;
   }
   RUN(conv_forward(c.st, c.cdt(), w.ntaps, x, ldx, B, H, W, w.cin_pad, w.wf, w.bias, w.cout, y, ldy, res, ldr, out_f32, 1.f, w.cin,
-                   (stt.mode || in_ups || res_ups) ? &stt : nullptr, c.u->sk_ws, c.u->sk_ws_floats));
+                   (stt.mode || in_ups || res_ups || tf_coef) ? &stt : nullptr, c.u->sk_ws, c.u->sk_ws_floats));
   return KDIP_OK;
 }
 // input-gradient: x here is dL/d(out) with >= cin_pad_b channels available (zero padded when cout % 32 != 0)
@@ -504,11 +506,14 @@ static int res_forward(Ctx& c, Layer& L, const void* x, long ldx, int B, int& H,
   const long ldo = dst ? ldd : L.cout;
   // GroupNorm + SiLU applied inside the consuming conv's input staging (second-generation kernel): the activated tensors
   // h1 / h3 are never written.  Not for downsampling blocks (the pool sits between SiLU and conv1) and small maps.
-  const bool f1 = L.mode != 1 && use_conv3(c, L.c1, B, Ho, Wo, ldx, L.cout, false, 0, 1) && (L.mode != 2 || !gn_small_eligible(c.dt, HW, L.cin));
-  const bool f2 = use_conv3(c, L.c2, B, Ho, Wo, L.cout, ldo, false, 0, 1);
+  // (split-precision mode: the same fusion in conv.hip's staging, for maps the streaming GroupNorm kernels would otherwise handle)
+  const bool x1 = conv_tf_eligible(c.cdt(), 9, Ho, Wo, L.c1.cin_pad) && !gn_small_eligible(c.dt, HW, L.cin);
+  const bool x2 = conv_tf_eligible(c.cdt(), 9, Ho, Wo, L.c2.cin_pad) && !gn_small_eligible(c.dt, HWo, L.cout);
+  const bool f1 = L.mode != 1 && (use_conv3(c, L.c1, B, Ho, Wo, ldx, L.cout, false, 0, 1) || x1) && (L.mode != 2 || !gn_small_eligible(c.dt, HW, L.cin));
+  const bool f2 = use_conv3(c, L.c2, B, Ho, Wo, L.cout, ldo, false, 0, 1) || x2;
   void* h1 = (fused_pool || f1) ? nullptr : u->scratch.alloc(es * B * HW * L.cin);
   Conv3Fuse fold1, fold2;                              // GroupNorm-coefficient folds of conv1 / conv2 (filled when the apply is fused)
-  if (!fused_pool) CK(gn_forward(c, x, ldx, B, HW, L.n1, nullptr, 1, h1, L.cin, &L.sv.coef1, &L.sv.mr1, 0, 0, nullptr, f1 ? &fold1 : nullptr));
+  if (!fused_pool) CK(gn_forward(c, x, ldx, B, HW, L.n1, nullptr, 1, h1, L.cin, &L.sv.coef1, &L.sv.mr1, 0, 0, nullptr, (f1 && c.dt == DT_BF16) ? &fold1 : nullptr));
   const void* cin_ptr = h1; const void* xs = x; long ldxs = ldx;
   if (L.mode == 1) {
     void* h1p = u->scratch.alloc(es * B * Ho * Wo * L.cin);
@@ -529,7 +534,7 @@ static int res_forward(Ctx& c, Layer& L, const void* x, long ldx, int B, int& H,
   else CK(conv_f(c, L.c1, cin_ptr, L.cin, B, Ho, Wo, h2, L.cout, nullptr, 0, 0, true, ups, 0));
   const float* film = film_all + L.emb_off;          // row b at film + b * emb_total
   void* h3 = f2 ? nullptr : u->scratch.alloc(es * B * HWo * L.cout);
-  CK(gn_forward(c, h2, L.cout, B, HWo, L.n2, film, 1, h3, L.cout, &L.sv.coef2, &L.sv.mr2, u->emb_total, 0, nullptr, f2 ? &fold2 : nullptr));
+  CK(gn_forward(c, h2, L.cout, B, HWo, L.n2, film, 1, h3, L.cout, &L.sv.coef2, &L.sv.mr2, u->emb_total, 0, nullptr, (f2 && c.dt == DT_BF16) ? &fold2 : nullptr));      // (the coefficient fold is conv3's)
   const void* S = xs; long ldS = ldxs;
   if (L.has_skip) {
     void* sk = u->scratch.alloc(es * B * HWo * L.cout);

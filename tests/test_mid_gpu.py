@@ -71,7 +71,7 @@ def test_unet_mid_forward_vjp_vs_reference(gold, mid):
         print(f"\nmid UNet {dt}: forward rel-max {eo:.2e}, VJP rel-max {ev:.2e}; conv tags {sorted(tags)}")
         if dt == "bf16":     # the point of this fixture: the second-generation kernel and its fusions ran
             assert {"conv3_gnf_s1", "conv3_gnb_s2"} <= tags or {"conv3_gnf_s1_res", "conv3_gnb_s2"} <= tags, tags
-            assert eo < 6e-2 and ev < 6e-2, (eo, ev)
+            assert eo < 4e-2 and ev < 6e-2, (eo, ev)          # 3 x measured (1.4e-2 / 2.0e-2)
         else:
             assert eo < UNET_BOUNDS[dt][0] and ev < UNET_BOUNDS[dt][1], (dt, eo, ev)
 
@@ -106,6 +106,6 @@ def test_guided_calls_mid_vs_reference(gold, mid, sigma_v):
         print(f"\nmid guided call sigma={sigma_v} {dt}: max-abs {err:.2e}, PSNR(hip, reference) min {min(ps):.1f} / median {sorted(ps)[B // 2]:.1f} dB")
         if dt == "bf16":
             assert any(tg.startswith("conv3_gn") for tg in tags), tags
-            assert min(ps) > 30.0, ps
+            assert min(ps) > (27.0 if sigma_v > 1 else 59.0), ps      # measured minima 32.4 / 64.8 dB: floor = measured - 5 dB
         else:
-            assert err < 2e-3, (dt, err)
+            assert err < 2e-4, (dt, err)      # measured <= 1.3e-5

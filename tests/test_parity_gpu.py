@@ -6,9 +6,10 @@ Tolerances (max-abs on images in [-1,1]):
   * f32 mode (exact-f32 MFMA, fp32 activations): 2e-3 on guided x0 estimates.  The guided call
     amplifies UNet round-off by sigma^2 / (sigma_s^2 + C) (x400 at sigma_s = 0.05), and the CG
     branch is only tol=1e-4 accurate in the reference itself.
-  * bf16 mode (production): reported as PSNR between HIP and oracle outputs, floor 30 dB on the
-    random-weight tiny model (bf16 operand rounding, 8 mantissa bits, through ~40 conv layers
-    and the VJP).
+  * bf16x3 mode (split-precision convs, csrc/conv.hip Mma<f32x3_t>): the same bounds as f32 everywhere.
+  * bf16 mode (throughput): reported as PSNR between HIP and reference outputs; floors = the measured
+    minima minus 5 dB per operator (bf16 operand rounding, 8 mantissa bits, through ~40 conv layers and
+    the VJP; a 10 x numerical regression costs 20 dB).
 """
 import numpy as np
 import pytest
@@ -181,6 +182,9 @@ GUIDED = [("I", "convert", {}), ("II", "convert", {}), ("II", "pgdm", {}), ("dps
           ("uncond", "convert", {}), ("dps+mle", "convert", dict(zeta=1.0))]
 
 
+BF16_CALL_PSNR_FLOOR = {"gaussian_blur": 39.0, "motion_blur": 29.5, "super_resolution": 33.0, "inpainting": 30.0}      # measured minima: 44.0 / 34.5 / 38.0 / 35.2 dB
+
+
 @pytest.mark.parametrize("name", ["gaussian_blur", "motion_blur", "super_resolution", "inpainting"])
 def test_guided_calls_golden(gold, tiny, name):
     import kdip_amd.condition as kc
@@ -204,10 +208,10 @@ def test_guided_calls_golden(gold, tiny, name):
                     err = float((hat - ref).abs().max())
                     worst[dt] = max(worst[dt], err)
                     assert err < 2e-3, (dt, name, guidance, cov, sigma_v, err)
-                else:
+                else:       # bf16: per-operator floor = the measured minimum over the 18 calls minus 5 dB (a 10 x numerical regression costs 20 dB)
                     p = psnr_db(hat, ref)
                     min_psnr = min(min_psnr, p)
-                    assert p > 30.0, (name, guidance, cov, sigma_v, p)
+                    assert p > BF16_CALL_PSNR_FLOOR[name], (name, guidance, cov, sigma_v, p)
     print(f"\n[{name}] f32 worst max-abs {worst['f32']:.2e}; bf16x3 worst max-abs {worst['bf16x3']:.2e}; bf16 min PSNR vs reference {min_psnr:.1f} dB")
 
 
@@ -668,7 +672,7 @@ def test_graph_redoes_unconverged_fixed_trip_replay(gold, tiny):
     lo = torch.tensor([0.12], device="cuda")
     ref = den(x, lo)
     need = max(hop.cg_iters)
-    assert need > 8, need                      # (otherwise 4 trips would be enough and the test would be vacuous)
+    assert need > 4, need                      # (otherwise 4 trips would be enough and the test would be vacuous)
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         out = gd(x, lo)
