@@ -73,7 +73,7 @@ def available_cores():
     return n
 
 
-REFERENCE_S_PER_CALL_8VCPU = 1.8     # the imported reference itself, build container, 8 vCPU, batch 1
+REF_VS_ORACLE = os.path.join(ROOT, "profiles", "r04", "ref_vs_oracle_cpu.json")     # oracle/measure_ref_vs_oracle.py (build container)
 
 
 def cpu_baseline(sig):
@@ -100,14 +100,19 @@ def cpu_baseline(sig):
         times[tag] = (time.perf_counter() - t0) / 6
     n_lo = 42
     sec_per_image = (CALLS_PER_IMAGE - n_lo) * times["hi"] + n_lo * times["lo"]
-    # cross-check against the imported reference's own figure (SURVEY 8d asks for +-10 % at equal core count: the reference is
-    # torch-CPU fp32 like the oracle, so per-call time scales with the cores torch may use)
-    scaled_ref = REFERENCE_S_PER_CALL_8VCPU * 8.0 / ncores
+    # cross-check that the port is a fair stand-in for the real reference (within 10 %): both timed on the SAME cores in
+    # the build container, where the reference can be imported (oracle/measure_ref_vs_oracle.py -> profiles/r04/ref_vs_oracle_cpu.json)
+    try:
+        rv = json.load(open(REF_VS_ORACLE))
+        cross = {"source": "profiles/r04/ref_vs_oracle_cpu.json (python -m oracle.measure_ref_vs_oracle in the build container: the imported "
+                           "reference and the oracle on the same %d cores, full-size batch-1 guided calls, best of 3)" % rv["cores"],
+                 "cores": rv["cores"], **{k: {kk: v[kk] for kk in ("reference_s_per_call", "oracle_s_per_call", "oracle_over_reference")}
+                                          for k, v in rv["calls"].items()}}
+    except Exception as e:
+        cross = {"error": repr(e)[:200]}
     return {"value": 1.0 / sec_per_image, "unit": "images/s", "cores": ncores, "kind": "port",
             "s_per_call_closed_form": round(times["hi"], 4), "s_per_call_cg": round(times["lo"], 4),
-            "reference_cross_check": {"reference_s_per_call_8vcpu_build_container": REFERENCE_S_PER_CALL_8VCPU,
-                                      "scaled_to_these_cores_s_per_call": round(scaled_ref, 3),
-                                      "oracle_over_scaled_reference": round(times["hi"] / scaled_ref, 3)},
+            "reference_cross_check": cross,
             "sample": "oracle (torch-CPU fp32 restatement, validated against the reference) at batch 1: 3 Heun steps = 6 "
                       "Type-I/Convert guided calls from sigma=%.3g (closed form) + 3 Heun steps = 6 calls from sigma=%.3g (CG "
                       "branch), extrapolated to 157 + 42 calls = 100 Heun steps" % (float(sig[10]), float(sig[95]))}
@@ -315,6 +320,25 @@ def main():
         L.check(lib.kdip_profile_enable(1))
         for i in (10, 95):
             ks.heun_step(den, start_state(parts[0], i), sig, i)
+        # ... and one pass over the operator / transform kernels of the path that this workload (Gaussian deblur, pixel basis) does
+        # not touch, on the same 8 x 3 x 256 x 256 planes: motion blur (FFT model), 4x SR (Resizer + its adjoint + FFT solver model),
+        # inpainting (gather / scatter / mask), Haar DWT / IDWT -- north_star judges them by HBM GB/s (`hbm_bound_classes.op_*`)
+        try:
+            from kdip_amd.transforms import OrthoTransform
+            xo = x0.contiguous()
+            np.random.seed(0)
+            ops = {n: km.get_operator(n, device=dev, **kw) for n, kw in (
+                ("motion_blur", dict(in_shape=(1, 3, S, S), kernel_size=61, intensity=0.5, sigma_s=0.05)),
+                ("super_resolution", dict(in_shape=(1, 3, S, S), scale_factor=4, sigma_s=0.05)),
+                ("inpainting", dict(sigma_s=0.05, mask_opt=dict(mask_type="random", mask_prob_range=(0.5, 0.5), image_size=S))))}
+            dwt = OrthoTransform("dwt")
+            for _ in range(3):
+                ym = ops["motion_blur"].forward(xo, noiseless=True); ops["motion_blur"].transpose(ym)
+                ys = ops["super_resolution"].forward(xo, noiseless=True); ops["super_resolution"].forward_adjoint(ys); ops["super_resolution"].transpose(ys)
+                yi, yif = ops["inpainting"].forward(xo, flatten=True); ops["inpainting"].transpose(yif, flatten=True)
+                dwt.inv(dwt(xo))
+        except Exception as e:
+            out["roofline_operator_pass_error"] = repr(e)[:200]
         torch.cuda.synchronize()
         n = lib.kdip_profile_num_classes()
         ms = (C.c_double * n)(); fl = (C.c_double * n)(); by = (C.c_double * n)(); la = (C.c_long * n)()
@@ -332,9 +356,9 @@ def main():
         key, (cnt, us, gf, mb) = max(grp.items(), key=lambda kv: kv[1][1])
         tflops = gf / us * 1e3 if us > 0 else 0.0          # GFLOP / us = PFLOP/s
         # HBM traffic of this (kernel, fusion mode, layer shape): rocprofv3 --pmc passes over the same in-network launches
-        # (tools/pmc_innetwork.sh -> profiles/r03_pmc_innetwork.json; FETCH_SIZE x 2 + WRITE_SIZE per MI355X_MICROARCH.md)
+        # (tools/pmc_innetwork.sh -> profiles/r04_pmc_innetwork.json; FETCH_SIZE x 2 + WRITE_SIZE per MI355X_MICROARCH.md)
         traffic, traffic_source, pmc_extra = None, None, {}
-        pmc = next((f for f in (os.path.join(ROOT, "profiles", t + "_pmc_innetwork.json") for t in ("r03", "r02")) if os.path.exists(f)), "")
+        pmc = next((f for f in (os.path.join(ROOT, "profiles", t + "_pmc_innetwork.json") for t in ("r04", "r03", "r02")) if os.path.exists(f)), "")
         if pmc:
             try:
                 e = json.load(open(pmc))["shapes"].get("|".join(key[1:]))
@@ -374,7 +398,10 @@ def main():
                                 "launches": int(la[k]), "avg_launch_us": round(ms[k] * 1e3 / max(la[k], 1), 2)},
             "all_conv_classes": {lib.kdip_profile_class_name(j).decode(): {"ms": round(ms[j], 3), "tflops": round(fl[j] / max(ms[j], 1e-9) / 1e9, 2), "launches": int(la[j])}
                                  for j in range(n) if la[j] > 0 and names[j].startswith("conv")},
-            # the GroupNorm streaming passes: algorithmic bytes / HIP-event time (HBM ~8 TB/s peak, ~6.3 TB/s achievable)
+            # the GroupNorm streaming passes and the operator / transform / point-wise kernels (op_*, pointwise): algorithmic bytes /
+            # HIP-event time against HBM (~8 TB/s peak, ~6.3 TB/s achievable); the op_* launches move 6 - 25 MB each, i.e. they are
+            # launch- / latency-bound at this batch
+            "hbm_peak_GBps": 8000.0,
             "hbm_bound_classes": {names[j]: {"ms": round(ms[j], 3), "GBps": round(by[j] / max(ms[j], 1e-9) / 1e6, 1), "launches": int(la[j])}
                                   for j in range(n) if la[j] > 0 and not names[j].startswith("conv")},
         }
@@ -427,6 +454,21 @@ def main():
     # end-to-end PSNR deviation from this mode is measured by tests/test_fullsize_gpu.py::test_e2e_bf16_vs_f32_psnr.
     if not args.no_f32_leg and env.world_size == 1 and args.dtype == "bf16" and B == 16:
         import subprocess
+        # the FAST tolerance-compliant mode: fp32 storage + split-precision convs (bf16 head + fp16 tails, 3 MFMAs per product), pinned to
+        # the reference at the same bounds as the exact-f32 mode (tests/test_parity_gpu.py, test_x3_gpu.py, test_fullsize_gpu.py)
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--dtype", "bf16x3", "--batch", str(B), "--streams", str(args.streams),
+                                "--steps", "20", "--warmup", "2", "--no-cpu-baseline", "--no-roofline", "--no-large-batch", "--no-f32-leg"],
+                               capture_output=True, text=True, timeout=900)
+            x3 = json.loads(r.stdout.strip().splitlines()[-1])
+            out["bf16x3_parity_mode"] = {"value": x3["value"], "unit": "images/s", "dtype": "bf16x3", "ms_per_step": x3["ms_per_step"], "steps": x3["steps"],
+                                         "bf16_over_bf16x3": round(images_per_s / x3["value"], 2),
+                                         "achieved_tflops_whole_step": x3["achieved_tflops_whole_step"],
+                                         "note": "same workload, protocol and code path (python bench.py --dtype bf16x3 --steps 20): fp32 activations, every conv as "
+                                                 "1 v_mfma_f32_32x32x16_bf16 + 2 v_mfma_f32_32x32x16_f16 per product with fp32 accumulation (conv error at the "
+                                                 "exact-f32 kernel's level): the mode that meets the 1e-3 dB tolerance at speed"}
+        except Exception as e:
+            out["bf16x3_parity_mode"] = {"error": repr(e)[:200]}
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--dtype", "f32", "--batch", str(B), "--streams", str(args.streams),
                                 "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-roofline", "--no-large-batch", "--no-f32-leg"],

@@ -47,7 +47,8 @@ void prof_end(hipStream_t st) {
 }
 static const char* kClassNames[PC_COUNT] = {"conv3x3_igemm_128x128", "conv3x3_igemm_128x64", "conv3x3_igemm_128x32",
                                             "conv1x1_igemm_128x128", "conv1x1_igemm_128x64", "conv1x1_igemm_128x32",
-                                            "gn_stats", "gn_apply", "gn_bwd_stats", "gn_bwd_apply"};
+                                            "gn_stats", "gn_apply", "gn_bwd_stats", "gn_bwd_apply",
+                                            "op_blur", "op_fft2", "op_otf", "op_dwt", "op_gather_scatter_mask", "op_resize", "pointwise"};
 }  // namespace kdip
 
 extern "C" {

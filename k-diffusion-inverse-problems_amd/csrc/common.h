@@ -143,10 +143,18 @@ inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- opt-in per-launch profiler (HIP events on the launch stream; used by bench.py's roofline leg) ----
 enum ProfClass { PC_CONV3_128x128 = 0, PC_CONV3_128x64, PC_CONV3_128x32, PC_CONV1_128x128, PC_CONV1_128x64,
-                 PC_CONV1_128x32, PC_GN_STATS, PC_GN_APPLY, PC_GN_BWD_STATS, PC_GN_BWD_APPLY, PC_COUNT };
+                 PC_CONV1_128x32, PC_GN_STATS, PC_GN_APPLY, PC_GN_BWD_STATS, PC_GN_BWD_APPLY,
+                 // operator / transform / sampler kernels on fp32 [B,3,S,S] planes (HBM-bound: algorithmic bytes = every tensor read or written once)
+                 PC_OP_BLUR, PC_OP_FFT, PC_OP_OTF, PC_OP_DWT, PC_OP_GATHER, PC_OP_RESIZE, PC_OP_POINTWISE, PC_COUNT };
 constexpr int PC_NUM_CONV = PC_GN_STATS;      // classes [0, PC_NUM_CONV) are MFMA convs (flops); the rest are HBM streaming passes (bytes)
 extern bool g_prof_on;
 void prof_begin(hipStream_t st, int cls, double flops, double bytes, const char* tag = nullptr, long d0 = 0, long d1 = 0, long d2 = 0, long d3 = 0);
 void prof_end(hipStream_t st);
+// brackets every launch of the enclosing scope (HIP events on `st`; nothing happens unless the profiler is on)
+struct ProfScope {
+  hipStream_t st;
+  ProfScope(hipStream_t s, int cls, double bytes, const char* tag, long d0 = 0, long d1 = 0, long d2 = 0, long d3 = 0) : st(s) { prof_begin(s, cls, 0, bytes, tag, d0, d1, d2, d3); }
+  ~ProfScope() { prof_end(st); }
+};
 
 }  // namespace kdip

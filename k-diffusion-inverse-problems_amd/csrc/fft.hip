@@ -100,6 +100,7 @@ static int fft2_N(hipStream_t st, const float2* tw, const void* in, int real_in,
 
 int fft2(hipStream_t st, const float2* tw256, int N, const void* in, int real_in, float2* tmp, void* out, int real_out,
          long planes, int inverse) {
+  ProfScope ps_(st, PC_OP_FFT, (double)planes * N * N * ((real_in ? 4.0 : 8.0) + 8.0 + 8.0 + (real_out ? 4.0 : 8.0)), "fft2", planes, N, real_in, real_out);      // two axis passes: in -> tmp -> out
   if (N == 256) return fft2_N<256>(st, tw256, in, real_in, tmp, out, real_out, planes, inverse);
   if (N == 64) return fft2_N<64>(st, tw256, in, real_in, tmp, out, real_out, planes, inverse);
   if (N == 16) return fft2_N<16>(st, tw256, in, real_in, tmp, out, real_out, planes, inverse);
@@ -125,6 +126,7 @@ __global__ void cmul_otf_kernel(float2* __restrict__ X, const float2* __restrict
   }
 }
 int cmul_otf(hipStream_t st, float2* X, const float2* FB, long nn, long planes, int conj) {
+  ProfScope ps_(st, PC_OP_OTF, (double)nn * planes * sizeof(float2) * 2 + (double)nn * sizeof(float2), "cmul_otf", planes, nn);
   hipLaunchKernelGGL(cmul_otf_kernel, dim3(pw_grid(nn * planes)), dim3(256), 0, st, X, FB, nn, nn * planes, conj);
   KDIP_LAUNCH_CHECK();
   return KDIP_OK;
@@ -142,6 +144,7 @@ __global__ void otf_solve_kernel(float2* __restrict__ R, const float2* __restric
   }
 }
 int otf_solve(hipStream_t st, float2* R, const float2* FB, long nn, long planes, float s2, float v) {
+  ProfScope ps_(st, PC_OP_OTF, (double)nn * planes * sizeof(float2) * 2 + (double)nn * sizeof(float2), "otf_solve", planes, nn);
   hipLaunchKernelGGL(otf_solve_kernel, dim3(pw_grid(nn * planes)), dim3(256), 0, st, R, FB, nn, nn * planes, s2, v);
   KDIP_LAUNCH_CHECK();
   return KDIP_OK;
@@ -190,6 +193,7 @@ __global__ void sr_solve_tile_kernel(const float2* __restrict__ Rs, const float*
 }
 int sr_solve_tile(hipStream_t st, const float2* Rs, const float* invW, const float2* FB, int N, int sf, long planes,
                   float s2, float v, float2* out) {
+  ProfScope ps_(st, PC_OP_OTF, (double)planes * N * N * sizeof(float2) + (double)planes * (N / sf) * (N / sf) * sizeof(float2), "sr_solve_tile", planes, N, sf);
   hipLaunchKernelGGL(sr_solve_tile_kernel, dim3(pw_grid(planes * (long)N * N)), dim3(256), 0, st, Rs, invW, FB, N, sf,
                      planes, s2, v, out);
   KDIP_LAUNCH_CHECK();

@@ -20,6 +20,7 @@ __global__ void axpby_kernel(const float* x, float a, const float* y, float b, l
   GRID_STRIDE(i, n) out[i] = y ? a * x[i] + b * y[i] : a * x[i];
 }
 int axpby(hipStream_t st, const float* x, float a, const float* y, float b, long n, float* out) {
+  ProfScope ps_(st, PC_OP_POINTWISE, (double)n * sizeof(float) * (y ? 3 : 2), "axpby", n);
   hipLaunchKernelGGL(axpby_kernel, dim3(pw_grid(n)), dim3(256), 0, st, x, a, y, b, n, out);
   KDIP_LAUNCH_CHECK(); return KDIP_OK;
 }
@@ -27,11 +28,13 @@ __global__ void mul_planes_kernel(const float* x, const float* m, long n, long m
   GRID_STRIDE(i, n) out[i] = x[i] * m[i % mn];
 }
 int mul_planes(hipStream_t st, const float* x, const float* m, long n, long mn, float* out) {
+  ProfScope ps_(st, PC_OP_GATHER, (double)n * sizeof(float) * 2 + (double)mn * sizeof(float), "mask_mul", n);
   hipLaunchKernelGGL(mul_planes_kernel, dim3(pw_grid(n)), dim3(256), 0, st, x, m, n, mn, out);
   KDIP_LAUNCH_CHECK(); return KDIP_OK;
 }
 __global__ void mul_elem_kernel(const float* x, const float* y, long n, float* out) { GRID_STRIDE(i, n) out[i] = x[i] * y[i]; }
 int mul_elem(hipStream_t st, const float* x, const float* y, long n, float* out) {
+  ProfScope ps_(st, PC_OP_POINTWISE, (double)n * sizeof(float) * 3, "mul", n);
   hipLaunchKernelGGL(mul_elem_kernel, dim3(pw_grid(n)), dim3(256), 0, st, x, y, n, out);
   KDIP_LAUNCH_CHECK(); return KDIP_OK;
 }
@@ -63,6 +66,7 @@ __global__ void gather_idx_kernel(const float* x, const long* idx, long nidx, lo
   GRID_STRIDE(i, (long)B * nidx) { long b = i / nidx, j = i % nidx; out[i] = x[b * per + idx[j]]; }
 }
 int gather_idx(hipStream_t st, const float* x, const long* idx, long nidx, long per, int B, float* out) {
+  ProfScope ps_(st, PC_OP_GATHER, (double)B * nidx * (2 * sizeof(float)) + (double)nidx * sizeof(long), "gather", B, nidx, per);
   hipLaunchKernelGGL(gather_idx_kernel, dim3(pw_grid((long)B * nidx)), dim3(256), 0, st, x, idx, nidx, per, B, out);
   KDIP_LAUNCH_CHECK(); return KDIP_OK;
 }
@@ -70,6 +74,7 @@ __global__ void scatter_idx_kernel(const float* y, const long* idx, long nidx, l
   GRID_STRIDE(i, (long)B * nidx) { long b = i / nidx, j = i % nidx; out[b * per + idx[j]] = y[i]; }
 }
 int scatter_idx(hipStream_t st, const float* y, const long* idx, long nidx, long per, int B, float* out) {
+  ProfScope ps_(st, PC_OP_GATHER, (double)B * nidx * sizeof(float) + (double)B * per * sizeof(float) + (double)nidx * sizeof(long), "scatter", B, nidx, per);
   KDIP_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(float) * B * per, st));
   hipLaunchKernelGGL(scatter_idx_kernel, dim3(pw_grid((long)B * nidx)), dim3(256), 0, st, y, idx, nidx, per, B, out);
   KDIP_LAUNCH_CHECK(); return KDIP_OK;
@@ -154,6 +159,7 @@ __global__ __launch_bounds__(256) void blur_sep63_kernel(const float* __restrict
 }
 
 int blur_sep_circ(hipStream_t st, const float* x, const float* k1d, int taps, int N, long planes, int axis, float* out) {
+  ProfScope ps_(st, PC_OP_BLUR, (double)planes * N * N * sizeof(float) * 2, "blur_sep", planes, N, taps, axis);
   KDIP_REQUIRE((N & (N - 1)) == 0 && N >= 16, "blur: N=%d must be a power of two", N);
   constexpr int LPB = 16;
   if ((taps & 1) && taps <= 63 && N % 8 == 0) {
@@ -203,6 +209,7 @@ __global__ __launch_bounds__(256) void blur_dense_kernel(const float* __restrict
   }
 }
 int blur_dense_circ(hipStream_t st, const float* x, const float* k2d, int ks, int N, long planes, int adjoint, float* out) {
+  ProfScope ps_(st, PC_OP_BLUR, (double)planes * N * N * sizeof(float) * 2, "blur_dense", planes, N, ks, adjoint);
   KDIP_REQUIRE((N & (N - 1)) == 0 && N >= 32 && (ks & 1), "blur: bad N=%d / ks=%d", N, ks);
   const int HS = 32 + 2 * (ks / 2);
   size_t lds = sizeof(float) * (HS * (HS + 1) + ks * ks);
@@ -230,6 +237,7 @@ __global__ void resize_axis_kernel(const float* __restrict__ x, const float* __r
 }
 int resize_axis(hipStream_t st, const float* x, const float* w, const int* fov, int taps, int n_in, int n_out, int other,
                 int axis, long planes, float* out) {
+  ProfScope ps_(st, PC_OP_RESIZE, (double)planes * other * ((double)n_in + n_out) * sizeof(float), "resize", planes, n_in, n_out, axis);
   hipLaunchKernelGGL(resize_axis_kernel, dim3(pw_grid(planes * (long)n_out * other)), dim3(256), 0, st, x, w, fov, taps, n_in,
                      n_out, other, axis, planes, out);
   KDIP_LAUNCH_CHECK(); return KDIP_OK;
@@ -251,6 +259,7 @@ __global__ void resize_axis_adj_kernel(const float* __restrict__ g, const float*
 }
 int resize_axis_adj(hipStream_t st, const float* g, const float* w, const int* fov, int taps, int n_in, int n_out, int other,
                     int axis, long planes, float* out) {
+  ProfScope ps_(st, PC_OP_RESIZE, (double)planes * other * ((double)n_in + n_out) * sizeof(float), "resize_adj", planes, n_in, n_out, axis);
   KDIP_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(float) * planes * n_in * other, st));
   hipLaunchKernelGGL(resize_axis_adj_kernel, dim3(pw_grid(planes * (long)n_out * other)), dim3(256), 0, st, g, w, fov, taps,
                      n_in, n_out, other, axis, planes, out);
@@ -337,6 +346,7 @@ __global__ void dwt_haar3_kernel(const float* __restrict__ x, int N, long planes
   }
 }
 int dwt_haar3(hipStream_t st, const float* x, int N, long planes, float* out) {
+  ProfScope ps_(st, PC_OP_DWT, (double)planes * N * N * sizeof(float) * 2, "dwt", planes, N);
   KDIP_REQUIRE(N % 8 == 0, "dwt: N=%d must be a multiple of 8", N);
   hipLaunchKernelGGL(dwt_haar3_kernel, dim3(pw_grid(planes * (N / 8) * (N / 8))), dim3(256), 0, st, x, N, planes, out);
   KDIP_LAUNCH_CHECK(); return KDIP_OK;
@@ -365,6 +375,7 @@ __global__ void idwt_haar3_kernel(const float* __restrict__ c, int N, long plane
   }
 }
 int idwt_haar3(hipStream_t st, const float* c, int N, long planes, float* out) {
+  ProfScope ps_(st, PC_OP_DWT, (double)planes * N * N * sizeof(float) * 2, "idwt", planes, N);
   KDIP_REQUIRE(N % 8 == 0, "idwt: N=%d must be a multiple of 8", N);
   hipLaunchKernelGGL(idwt_haar3_kernel, dim3(pw_grid(planes * (N / 8) * (N / 8))), dim3(256), 0, st, c, N, planes, out);
   KDIP_LAUNCH_CHECK(); return KDIP_OK;
@@ -405,6 +416,7 @@ __global__ void x0_v1_kernel(const float* __restrict__ uo, const float* __restri
 }
 int x0_epilogue_v1(hipStream_t st, const float* unet_out, const float* x, int B, long HW, X0Params p, float* x0_mean,
                    float* x0_raw, float* var) {
+  ProfScope ps_(st, PC_OP_POINTWISE, (double)B * HW * sizeof(float) * (6 + 3 + 3 + 3 + (var ? 3 : 0)), "x0_epilogue_v1", B, HW);
   hipLaunchKernelGGL(x0_v1_kernel, dim3(pw_grid((long)B * 3 * HW)), dim3(256), 0, st, unet_out, x, B, HW, p, x0_mean, x0_raw, var);
   KDIP_LAUNCH_CHECK(); return KDIP_OK;
 }
@@ -441,6 +453,7 @@ __global__ void cot_v1_kernel(const float* __restrict__ gh, const float* __restr
 }
 int vjp_cotangent_v1(hipStream_t st, const float* ghat, const float* x0_raw, int B, long HW, float sqrt_recipm1, float* cot6,
                      float* g_raw) {
+  ProfScope ps_(st, PC_OP_POINTWISE, (double)B * HW * sizeof(float) * (3 + 3 + 6 + 3), "cotangent_v1", B, HW);
   hipLaunchKernelGGL(cot_v1_kernel, dim3(pw_grid((long)B * 3 * HW)), dim3(256), 0, st, ghat, x0_raw, B, HW, sqrt_recipm1, cot6, g_raw);
   KDIP_LAUNCH_CHECK(); return KDIP_OK;
 }
@@ -463,6 +476,7 @@ __global__ void combine_kernel(const float* x0, const float* gd, float a, const 
 }
 int guidance_combine(hipStream_t st, const float* x0_mean, const float* g_direct, float a, const float* unet_vjp, float b,
                      float coef, long n, float* hat) {
+  ProfScope ps_(st, PC_OP_POINTWISE, (double)n * sizeof(float) * (3 + (unet_vjp ? 1 : 0)), "combine", n);
   hipLaunchKernelGGL(combine_kernel, dim3(pw_grid(n)), dim3(256), 0, st, x0_mean, g_direct, a, unet_vjp, b, coef, n, hat);
   KDIP_LAUNCH_CHECK(); return KDIP_OK;
 }
@@ -488,6 +502,7 @@ __global__ void dot_kernel(const float* __restrict__ a, const float* __restrict_
   if (threadIdx.x == 0) atomicAdd(&out[bidx], sh[0] + sh[1] + sh[2] + sh[3]);
 }
 int cg_dot(hipStream_t st, const float* a, const float* b, int B, long per, double* out) {
+  ProfScope ps_(st, PC_OP_POINTWISE, (double)B * per * sizeof(float) * 2, "cg_dot", B, per);
   KDIP_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(double) * B, st));
   int chunks = (int)((per + 4095) / 4096); if (chunks > 256) chunks = 256; if (chunks < 1) chunks = 1;
   hipLaunchKernelGGL(dot_kernel, dim3(chunks, B), dim3(256), 0, st, a, b, per, out);
@@ -521,6 +536,7 @@ __global__ void euler_kernel(const float* x, const float* den, float sh, float d
   GRID_STRIDE(i, n) { float d = (x[i] - den[i]) / sh; out[i] = x[i] + d * dt; }
 }
 int sampler_euler(hipStream_t st, const float* x, const float* den, float sigma_hat, float dt, long n, float* out) {
+  ProfScope ps_(st, PC_OP_POINTWISE, (double)n * sizeof(float) * 3, "sampler_euler", n);
   hipLaunchKernelGGL(euler_kernel, dim3(pw_grid(n)), dim3(256), 0, st, x, den, sigma_hat, dt, n, out);
   KDIP_LAUNCH_CHECK(); return KDIP_OK;
 }
@@ -532,6 +548,7 @@ __global__ void heun_kernel(const float* x, const float* d1, const float* x2, co
 }
 int sampler_heun(hipStream_t st, const float* x, const float* den1, const float* x2, const float* den2, float sigma_hat,
                  float sigma_next, float dt, long n, float* out) {
+  ProfScope ps_(st, PC_OP_POINTWISE, (double)n * sizeof(float) * 5, "sampler_heun", n);
   hipLaunchKernelGGL(heun_kernel, dim3(pw_grid(n)), dim3(256), 0, st, x, den1, x2, den2, sigma_hat, sigma_next, dt, n, out);
   KDIP_LAUNCH_CHECK(); return KDIP_OK;
 }
@@ -576,6 +593,7 @@ __global__ void cg_update_p_kernel(CgState s, const float* r, float* p, long per
   GRID_STRIDE(i, n) { int b = (int)(i / per); if (s.active[b]) p[i] = r[i] + s.beta[b] * p[i]; }
 }
 int cg_update_p(hipStream_t st, CgState s, const float* r, float* p, int B, long per) {
+  ProfScope ps_(st, PC_OP_POINTWISE, (double)B * per * sizeof(float) * 3, "cg_update_p", B, per);
   hipLaunchKernelGGL(cg_update_p_kernel, dim3(pw_grid((long)B * per)), dim3(256), 0, st, s, r, p, per, (long)B * per);
   KDIP_LAUNCH_CHECK(); return KDIP_OK;
 }
@@ -596,6 +614,7 @@ __global__ void cg_update_xr_kernel(CgState s, float* x, float* r, const float* 
   }
 }
 int cg_update_xr(hipStream_t st, CgState s, float* x, float* r, const float* p, const float* q, int B, long per) {
+  ProfScope ps_(st, PC_OP_POINTWISE, (double)B * per * sizeof(float) * 6, "cg_update_xr", B, per);
   hipLaunchKernelGGL(cg_update_xr_kernel, dim3(pw_grid((long)B * per)), dim3(256), 0, st, s, x, r, p, q, per, (long)B * per);
   KDIP_LAUNCH_CHECK(); return KDIP_OK;
 }
