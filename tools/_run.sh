@@ -1,4 +1,5 @@
-mkdir -p gpurun_out/r04h
-python -m pytest tests/test_parity_gpu.py tests/test_harness_gpu.py tests/test_mid_gpu.py tests/test_x3_gpu.py -q -m gpu -s -k "guided_calls_golden or sampler_golden or churn or harness_parity or mid or x3 or graph or second_vjp or custom_mat" 2>&1 | grep -E "^\[|ode, tiny|churn|harness.*x3|mid |passed|failed|assert|Error" | cut -c1-300 > gpurun_out/r04h/parity.log
-python -m pytest tests/test_fullsize_gpu.py -q -m gpu -s -k "e2e or configs_fullsize" 2>&1 | grep -E "^e2e|^cfg|passed|failed|assert" | cut -c1-600 > gpurun_out/r04h/fullsize.log
-python bench.py --dtype bf16x3 --steps 10 --warmup 2 --no-cpu-baseline --no-large-batch --no-f32-leg --no-graph-leg > gpurun_out/r04h/x3_bench.json 2> gpurun_out/r04h/x3_bench.err
+mkdir -p gpurun_out/r04k
+for i in 1 2 3; do python -m pytest tests/test_kernels_gpu.py -q -m gpu -k "conv" 2>&1 | tail -1; done > gpurun_out/r04k/unit.log
+python -m pytest tests/test_parity_gpu.py -q -m gpu -k "guided_calls_golden or sampler_golden" 2>&1 | tail -1 >> gpurun_out/r04k/unit.log
+for sh in "8 512 512 8 8 9" "8 512 512 16 16 9" "8 256 256 16 16 9" "8 1024 512 8 8 9"; do for v in "" _sk0; do echo -n "[$v] "; KDIP_LIB_PATH=$GRAFT_REPO_ROOT/k-diffusion-inverse-problems_amd/libkdip_hip$v.so python tools/conv_micro.py $sh 30 1 2>&1 | grep -v amdgpu.ids; done; done > gpurun_out/r04k/micro.log 2>&1
+KDIP_AB_BATCH=16 KDIP_AB_STEPS=20 bash tools/ab_variants.sh "" _sk0 > gpurun_out/r04k/ab.log 2>&1
