@@ -129,6 +129,7 @@ struct ConvParams {
   int cin_real;                   // un-padded input channels (profiling / algorithmic FLOPs only)
   int vec_epilogue;               // LDS-transposed 4-channel-per-lane stores
   int fast_epilogue;              // bf16 out, all strides / pointers 16-byte friendly: 8-channel-per-lane stores (below)
+  int fast_epilogue32;            // fp32 storage out (f32 / split-precision modes), 16-byte friendly: epilogue_f32_fast
   float* sk_ws; long sk_ws_floats; int sk_splits;    // split-K (small-spatial layers): blockIdx.y owns a K-chunk range, fp32 partial sums are
                                   // atomically added to sk_ws [B*H*W][Cout] (zero on entry); the LAST block to arrive at a tile (ticket counter
   int* sk_tickets;                // sk_tickets[tile], zero on entry) adds bias / residual, casts, stores and re-zeroes its part of sk_ws: one launch
@@ -195,6 +196,9 @@ constexpr int KC = 32;            // input channels per B-pipeline stage (one ta
 #endif
 #ifndef KDIP_FAST_EPI
 #define KDIP_FAST_EPI 1
+#endif
+#ifndef KDIP_FAST_EPI32
+#define KDIP_FAST_EPI32 1    // fp32-storage convs take epilogue_f32_fast where the shape allows (0: the generic LDS-transposed path, A/B builds)
 #endif
 #ifndef KDIP_PERSIST
 #define KDIP_PERSIST 0       // 1: persistent 3x3 bf16 launches that stage the next tile's first patch during the last K chunk.
@@ -397,6 +401,124 @@ __device__ __forceinline__ void epilogue_bf16_fast(const ConvParams& p, f32x16 (
         atomicAdd(&sred[(wn * NT * 8 + lane * 2 + h) * 2], s1[h]);
         atomicAdd(&sred[(wn * NT * 8 + lane * 2 + h) * 2 + 1], s2[h]);
       }
+    }
+    __syncthreads();
+    if (tid < BN / 4) {
+      const int n = ntb * BN + tid * 4;
+      double* dst = p.st_sums + ((long)img0 * 32 + n / cpg) * 2;
+      atomicAdd(dst, (double)sred[tid * 2]);
+      atomicAdd(dst + 1, (double)sred[tid * 2 + 1]);
+    }
+  }
+}
+
+// ---- fp32-storage fast epilogue (f32 parity mode and the split-precision mode) ---------------
+// The same structure as epilogue_bf16_fast for 4-byte elements: one branch-free code path per (residual, statistics mode); a lane
+// owns 4 consecutive channels of one pixel (16-byte loads / stores), the residual rows of a whole m-tile are requested before the
+// transpose, the GroupNorm-backward sums run as a second sweep over the lane's own stored values.  (The generic LDS-transposed path
+// below keeps its loads inside the store loop behind wave-uniform branches -- a full memory round trip per pass; that did not matter
+// while the exact-f32 MFMAs were the bottleneck, it does for the 5 x shorter K loop of the split-precision mode.)
+template <int WAVES_M, int WAVES_N, int MT, int NT, bool RES, int MODE>
+__device__ __forceinline__ void epilogue_f32_fast(const ConvParams& p, f32x16 (&acc)[MT][NT], float alpha, unsigned char* smem, int tid, int lane, int wave,
+                                                  int wm, int wn, int nt0, int ntb, int img0, int y0, int x0) {
+  constexpr int BN = WAVES_N * NT * 32;
+  constexpr int RS = NT * 32 * 4 + 16;               // fp32 row stride of the per-wave region
+  constexpr int LPR = NT * 8;                        // lanes (4-channel vectors) per pixel row
+  constexpr int RPI = 64 / LPR;                      // pixel rows per pass
+  constexpr int NPASS = 32 / RPI;
+  unsigned char* creg = smem + wave * 32 * RS;
+  float* sred = (float*)(smem + WAVES_M * WAVES_N * 32 * RS);     // [BN/4][2] block-level stats combine
+  const int vec = lane % LPR, rowl = lane / LPR;
+  const int nl = nt0 * 32 + vec * 4;                 // this lane's 4 output channels (never straddle a group: cpg % 4 == 0)
+  const int cpg = p.Cout >> 5;
+  const float* res = (const float*)p.res;
+  const float* sx = (const float*)p.st_x;
+  float* yout = (float*)p.y;
+  float s1 = 0.f, s2 = 0.f;
+  if (MODE) {
+    if (tid < BN / 4 * 2) sred[tid] = 0.f;
+  }
+  float bv[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bv[nt] = p.bias ? p.bias[(nt0 + nt) * 32 + (lane & 31)] : 0.f;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int pix[NPASS];
+    float4 rres[NPASS];
+#pragma unroll
+    for (int it = 0; it < NPASS; ++it) {
+      const int m = (wm * MT + mt) * 32 + it * RPI + rowl;
+      const int tb = m >> p.lgTHW, rr = m & ((1 << p.lgTHW) - 1);
+      const int ty = rr >> p.lgTW, tx = rr & (p.TW - 1);
+      pix[it] = ((img0 + tb) * p.H + (y0 + ty)) * p.W + (x0 + tx);
+      if (RES) {
+        const int rp = p.res_ups ? ((img0 + tb) * (p.H >> 1) + ((y0 + ty) >> 1)) * (p.W >> 1) + ((x0 + tx) >> 1) : pix[it];
+        rres[it] = *(const float4*)(res + (long)rp * p.ldr + nl);
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        *(float*)(creg + row * RS + (nt * 32 + (lane & 31)) * 4) = acc[mt][nt][r] * alpha + bv[nt];
+      }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+    for (int it = 0; it < NPASS; ++it) {
+      const int row = it * RPI + rowl;
+      float4 v = *(const float4*)(creg + row * RS + vec * 16);
+      if (RES) { v.x += rres[it].x; v.y += rres[it].y; v.z += rres[it].z; v.w += rres[it].w; }
+      *(float4*)(yout + (long)pix[it] * p.ldy + nl) = v;
+      if (MODE == 1) {
+        s1 += (v.x + v.y) + (v.z + v.w);
+        s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+  if (MODE == 2) {
+    // GroupNorm-backward sums in a second sweep, once the accumulators are dead: every lane re-reads exactly the dy values it
+    // stored itself (program order, L2-hot) next to the x rows, 4 passes per batch in flight
+    const float4* cf = (const float4*)(p.st_coef + ((long)img0 * p.Cout + nl) * 2);
+    const float4 c0 = cf[0], c1 = cf[1];
+    const float ca[4] = {c0.x, c0.z, c1.x, c1.z}, cb[4] = {c0.y, c0.w, c1.y, c1.w};
+    const float2 mrv = *(const float2*)(p.st_mr + ((long)img0 * 32 + nl / cpg) * 2);
+    constexpr int SB = (MT * NPASS) % 4 == 0 ? 4 : 2;
+#pragma unroll 1
+    for (int q0 = 0; q0 < MT * NPASS; q0 += SB) {
+      float4 rd[SB], rx[SB];
+#pragma unroll
+      for (int j = 0; j < SB; ++j) {
+        const int m = wm * MT * 32 + (q0 + j) * RPI + rowl;
+        const int tb = m >> p.lgTHW, rr = m & ((1 << p.lgTHW) - 1);
+        const int ty = rr >> p.lgTW, tx = rr & (p.TW - 1);
+        const long px = ((long)(img0 + tb) * p.H + (y0 + ty)) * p.W + (x0 + tx);
+        rd[j] = *(const float4*)(yout + px * p.ldy + nl);
+        rx[j] = *(const float4*)(sx + px * p.st_ldx + nl);
+      }
+#pragma unroll
+      for (int j = 0; j < SB; ++j) {
+        const float vv[4] = {rd[j].x, rd[j].y, rd[j].z, rd[j].w}, xv[4] = {rx[j].x, rx[j].y, rx[j].z, rx[j].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float z = ca[e] * xv[e] + cb[e];
+          const float dz = p.st_silu ? vv[e] * silu_grad_f(z) : vv[e];
+          const float adz = ca[e] * dz;
+          s1 += adz;
+          s2 += adz * (xv[e] - mrv.x) * mrv.y;
+        }
+      }
+    }
+  }
+  if (MODE) {
+    // rows -> lanes sharing `vec`; then waves -> LDS; then one fp64 atomic pair per 4-channel vector
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    __syncthreads();                                  // sred zeroed, all waves past their creg use
+    if (lane < LPR) {
+      atomicAdd(&sred[(wn * LPR + lane) * 2], s1);
+      atomicAdd(&sred[(wn * LPR + lane) * 2 + 1], s2);
     }
     __syncthreads();
     if (tid < BN / 4) {
@@ -850,6 +972,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
       continue;
     }
   }
+  if constexpr (sizeof(T) == 4) {
+    if (KDIP_FAST_EPI32 && p.fast_epilogue32 && (ntb + 1) * BN <= p.Cout) {     // block-uniform
+#define KDIP_EPI32(R, M) epilogue_f32_fast<WAVES_M, WAVES_N, MT, NT, R, M>(p, acc, alpha, smem, tid, lane, wave, wm, wn, nt0, ntb, img0, y0, x0)
+      if (p.res) {
+        if (p.st_mode == 0) KDIP_EPI32(true, 0); else if (p.st_mode == 1) KDIP_EPI32(true, 1); else KDIP_EPI32(true, 2);
+      } else {
+        if (p.st_mode == 0) KDIP_EPI32(false, 0); else if (p.st_mode == 1) KDIP_EPI32(false, 1); else KDIP_EPI32(false, 2);
+      }
+#undef KDIP_EPI32
+      KDIP_STAMP(3);
+      continue;
+    }
+  }
   const T* res = (const T*)p.res;
   if (p.vec_epilogue) {
     // Fast path (Cout % 4 == 0): each wave transposes its fp32 accumulators through LDS so that a
@@ -1065,6 +1200,9 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
   p.fast_epilogue = KDIP_FAST_EPI && sizeof(T) == 2 && !p.out_f32 && p.vec_epilogue && p.Cout % 8 == 0 && p.ldy % 8 == 0 && (uintptr_t)p.y % 16 == 0 &&
                     (!p.res || (p.ldr % 8 == 0 && (uintptr_t)p.res % 16 == 0)) && p.B % TB == 0 &&
                     (p.st_mode != 2 || (p.st_ldx % 8 == 0 && (uintptr_t)p.st_x % 16 == 0 && (uintptr_t)p.st_coef % 16 == 0 && (uintptr_t)p.st_mr % 8 == 0));
+  p.fast_epilogue32 = sizeof(T) == 4 && p.vec_epilogue && (uintptr_t)p.y % 16 == 0 && (!p.res || (uintptr_t)p.res % 16 == 0) && p.B % TB == 0 &&
+                      (p.st_mode != 2 || (p.st_ldx % 4 == 0 && (uintptr_t)p.st_x % 16 == 0 && (uintptr_t)p.st_coef % 16 == 0 && (uintptr_t)p.st_mr % 8 == 0 && ((p.Cout >> 5) % 4) == 0)) &&
+                      (p.st_mode == 0 || ((p.Cout >> 5) % 4) == 0);
   if (p.st_mode && !(p.vec_epilogue && TB == 1 && p.Cout % 32 == 0 && ((p.Cout >> 5) % 4) == 0))
     return set_error(KDIP_ERR_UNSUPPORTED, "conv: fused GroupNorm statistics not available for this shape");
   int nblkN = cdiv(p.ntilesN * 32, BN);
