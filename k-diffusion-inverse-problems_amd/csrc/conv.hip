@@ -241,6 +241,9 @@ constexpr int KC = 32;            // input channels per B-pipeline stage (one ta
 #ifndef KDIP_X3_OCC
 #define KDIP_X3_OCC 2        // split-precision 128x128 tiles: resident blocks per CU the register budget is set for
 #endif
+#ifndef KDIP_X3_TW
+#define KDIP_X3_TW 16        // patch width of the split-precision instantiations
+#endif
 #ifndef KDIP_X3_SUBS1
 #define KDIP_X3_SUBS1 1      // split-precision 1x1 convs: 32-channel sub-chunks staged per barrier (2 = 102 KB of LDS, one block per CU: 404 vs 249 us
                              // on the 128 -> 256 @ 256x256 skip conv)
@@ -1169,7 +1172,8 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
   // 32-pixel-wide patches: an MFMA m-tile (32 rows) is one patch row, so the 16-lane groups of
   // ds_read_b128 see 16 consecutive pixels (5-slot stride -> conflict free); 16-wide patches put two
   // patch rows in one m-tile and collide on 2 of 16 slots.
-  int TW = p.W < KDIP_TW ? p.W : KDIP_TW;
+  const int tw_pref = std::is_same<T, f32x3_t>::value ? KDIP_X3_TW : KDIP_TW;
+  int TW = p.W < tw_pref ? p.W : tw_pref;
   int TH = p.H < BM / TW ? p.H : BM / TW;
   int TB = BM / (TH * TW);
   auto ispow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
