@@ -83,6 +83,17 @@ def test_imagenet_unet_fullsize():
     e2 = float((vjp.cpu() - vjp_ref).abs().max() / vjp_ref.abs().max())
     print(f"\nImageNet-256 UNet f32: fwd rel err {e1:.2e}, vjp rel err {e2:.2e}")
     assert e1 < 5e-4 and e2 < 5e-4
+    # the split-precision mode on the same architecture (256 base channels, 4 - 16 heads, fp32 attention GEMMs): the f32 bound
+    import kdip_amd.unet as ku
+    del m
+    torch.cuda.empty_cache()
+    m3 = ku.UNetModel(dtype="bf16x3", **ku.IMAGENET_CONFIG); m3.load_state_dict(sd)
+    out3, _, _ = m3.forward_raw(x.cuda(), t.cuda())
+    vjp3 = m3.vjp(cot.cuda())
+    e13 = float((out3.cpu() - out_ref.detach()).abs().max() / out_ref.abs().max())
+    e23 = float((vjp3.cpu() - vjp_ref).abs().max() / vjp_ref.abs().max())
+    print(f"ImageNet-256 UNet bf16x3: fwd rel err {e13:.2e}, vjp rel err {e23:.2e}")
+    assert e13 < 5e-4 and e23 < 5e-4
 
 
 @pytest.mark.parametrize("sigma_v", [1.5, 0.12])

@@ -305,3 +305,13 @@ def test_checkpoint_layouts_on_disk(tmp_path):
     assert all(torch.equal(got[k], sd[k]) for k in sd)
     shapes, _ = ku.state_dict_shapes(out_cov=True, **cfg)
     assert all(tuple(got[k].shape) == tuple(shapes[k]) for k in shapes)
+
+
+def test_dtype_names_match_the_header():
+    """kdip_amd._lib.DTYPES <-> include/kdip.h (KDIP_F32 / KDIP_BF16 / KDIP_BF16X3)."""
+    import re
+    import kdip_amd._lib as L
+    hdr = open(os.path.join(ROOT, "include", "kdip.h")).read()
+    for name, key in (("KDIP_F32", "f32"), ("KDIP_BF16", "bf16"), ("KDIP_BF16X3", "bf16x3")):
+        m = re.search(name + r"\s*=\s*(\d+)", hdr)
+        assert m and int(m.group(1)) == L.DTYPES[key], name

@@ -227,11 +227,12 @@ def test_guided_calls_v2_golden(gold, tiny):
             for sigma_v in (1.5, 0.12):
                 x = (x0 + sigma_v * torch.randn(1, 3, 64, 64, generator=torch.Generator().manual_seed(11))).cuda()
                 ref = T(g[f"{name}|{guidance}|v2|{sigma_v}"])
-                den = ke.OpenAIDenoiserV2(models["f32"], D)
-                m = kc.ConditionOpenAIDenoiserV2(den, operator=hop, measurement=meas, guidance=guidance,
-                                                 mle_sigma_thres=1.0, device="cuda").eval()
-                hat = m(x, torch.tensor([sigma_v], device="cuda")).cpu()
-                assert float((hat - ref).abs().max()) < 2e-3, (name, guidance, sigma_v)
+                for dt in ("f32", "bf16x3"):       # (the out_cov 1x1 head and the fractional-t path in both exact modes)
+                    den = ke.OpenAIDenoiserV2(models[dt], D)
+                    m = kc.ConditionOpenAIDenoiserV2(den, operator=hop, measurement=meas, guidance=guidance,
+                                                     mle_sigma_thres=1.0, device="cuda").eval()
+                    hat = m(x, torch.tensor([sigma_v], device="cuda")).cpu()
+                    assert float((hat - ref).abs().max()) < 2e-3, (dt, name, guidance, sigma_v)
 
 
 def test_v2_dwt_autoI_vs_oracle(gold, tiny):
