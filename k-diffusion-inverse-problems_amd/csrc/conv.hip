@@ -24,6 +24,7 @@
 #include <mutex>
 #include <type_traits>
 #include <math.h>
+#include <stdlib.h>
 #include "common.h"
 #include "kernels.h"
 
@@ -1315,6 +1316,12 @@ static int launch_T(ConvParams& p, hipStream_t st) {
   return launch_cfg<T, NTAPS, 2, 2, 2, 2>(p, st);
 #endif
   const int npad = p.ntilesN * 32;
+  {   // tuning aid (tools/): KDIP_TILE_FORCE = 1 | 2 | 3 forces the 128x128 / 128x64 / 128x32 tile configuration
+    static const int force = [] { const char* e = getenv("KDIP_TILE_FORCE"); return e ? atoi(e) : 0; }();
+    if (force == 1 && npad >= 128) return launch_cfg<T, NTAPS, 2, 2, 2, 2>(p, st);
+    if (force == 2 && npad >= 64) return launch_cfg<T, NTAPS, 2, 2, 2, 1>(p, st);
+    if (force == 3) return launch_cfg<T, NTAPS, 4, 1, 1, 1>(p, st);
+  }
   // All tiles are 128 pixels tall; pick the widest N tile that still gives >= 2 blocks per CU.
   // Small-spatial layers (8x8 ... 32x32) are weight-streaming / latency bound: more, narrower
   // blocks spread the weight reads over more CUs.
