@@ -397,7 +397,7 @@ def main():
         fusion = {"conv3": "plain", "conv3_gnf": "GroupNorm+SiLU fused into the input staging", "conv3_gnb": "GroupNorm backward fused into the input staging"}
         tagparts = key[1].split("_")
         base = "_".join(tagparts[:2]) if len(tagparts) > 1 and tagparts[1] in ("gnf", "gnb") else tagparts[0]
-        desc = fusion.get(base, "first-generation kernel (conv.hip)") + ("; GroupNorm forward sums of the output in the epilogue" if "s1" in tagparts else "") + \
+        desc = fusion.get(base, "first-generation kernel (conv.hip)" + (": split precision, 1 v_mfma_f32_32x32x16_bf16 + 2 v_mfma_f32_32x32x16_f16 per product" if args.dtype == "bf16x3" else "")) + ("; GroupNorm forward sums of the output in the epilogue" if "s1" in tagparts else "") + \
             ("; GroupNorm backward sums of the output in the epilogue" if "s2" in tagparts else "") + ("; residual add" if "res" in tagparts else "")
         names = [lib.kdip_profile_class_name(j).decode() for j in range(n)]
         k = max((j for j in range(n) if names[j].startswith("conv")), key=lambda j: ms[j])
@@ -481,12 +481,19 @@ def main():
         # the reference at the same bounds as the exact-f32 mode (tests/test_parity_gpu.py, test_x3_gpu.py, test_fullsize_gpu.py)
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--dtype", "bf16x3", "--batch", str(B), "--streams", str(args.streams),
-                                "--steps", "20", "--warmup", "2", "--no-cpu-baseline", "--no-roofline", "--no-large-batch", "--no-f32-leg"],
+                                "--steps", "20", "--warmup", "2", "--no-cpu-baseline", "--no-large-batch", "--no-f32-leg"],
                                capture_output=True, text=True, timeout=900)
             x3 = json.loads(r.stdout.strip().splitlines()[-1])
+            x3r = x3.get("roofline", {})
             out["bf16x3_parity_mode"] = {"value": x3["value"], "unit": "images/s", "dtype": "bf16x3", "ms_per_step": x3["ms_per_step"], "steps": x3["steps"],
                                          "bf16_over_bf16x3": round(images_per_s / x3["value"], 2),
                                          "achieved_tflops_whole_step": x3["achieved_tflops_whole_step"],
+                                         # dominant kernel of THIS mode, measured live like `roofline` above: algorithmic TFLOP/s (one product per MAC) and the
+                                         # MFMA work it stands for (three 16-bit MFMAs per product) against the 2.5 PFLOP/s dense peak
+                                         "roofline": {"kernel": x3r.get("kernel"), "achieved": x3r.get("achieved"), "unit": "TFLOP/s", "avg_launch_us": x3r.get("avg_launch_us"),
+                                                      "mfma_work_frac_of_peak": round(3.0 * x3r["achieved"] / BF16_MFMA_PEAK_TFLOPS, 4) if x3r.get("achieved") else None,
+                                                      "all_conv_classes": x3r.get("all_conv_classes"), "hbm_bound_classes": {k: v for k, v in (x3r.get("hbm_bound_classes") or {}).items() if k.startswith("gn")},
+                                                      "pmc_micro": "profiles/r04/pmc_x3_conv_micro.json (MFMA busy 0.585 at 1.81 GHz, traffic 1.11 x algorithmic)"},
                                          "note": "same workload, protocol and code path (python bench.py --dtype bf16x3 --steps 20): fp32 activations, every conv as "
                                                  "1 v_mfma_f32_32x32x16_bf16 + 2 v_mfma_f32_32x32x16_f16 per product with fp32 accumulation (conv error at the "
                                                  "exact-f32 kernel's level): the mode that meets the 1e-3 dB tolerance at speed"}

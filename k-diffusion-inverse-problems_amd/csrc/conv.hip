@@ -242,6 +242,9 @@ constexpr int KC = 32;            // input channels per B-pipeline stage (one ta
 #ifndef KDIP_X3_OCC
 #define KDIP_X3_OCC 2        // split-precision 128x128 tiles: resident blocks per CU the register budget is set for
 #endif
+#ifndef KDIP_X3_TF_APF
+#define KDIP_X3_TF_APF 1     // GroupNorm-staging instantiation: 1 = A-fragment prefetch + one weight stage in flight; 0 = no prefetch + two stages
+#endif
 #ifndef KDIP_X3_TW
 #define KDIP_X3_TW 16        // patch width of the split-precision instantiations
 #endif
@@ -783,7 +786,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
 #pragma unroll
         for (int pl = 0; pl < NPB; ++pl) dst[ks][nt][pl] = bptr(tp, (long)c32 * KS + ks, nt)[pl * 64];
   };
-  constexpr int BD = X3 ? ((NTAPS == 9 && !TFM) ? KDIP_X3_B_DEPTH : 1) : (MT * NT <= 2 && sizeof(T) == 2 && NTAPS == 9) ? KDIP_B_DEPTH_SMALL : KDIP_B_DEPTH;   // stages ahead
+  // the staging-transform instantiation trades the A-fragment prefetch (KDIP_X3_TF_APF 0: 48 registers) for the second weight stage
+  constexpr bool APF = KDIP_A_PREFETCH && !(X3 && TFM && !KDIP_X3_TF_APF);
+  constexpr int BD = X3 ? ((NTAPS == 9 && (!TFM || !KDIP_X3_TF_APF)) ? KDIP_X3_B_DEPTH : 1) : (MT * NT <= 2 && sizeof(T) == 2 && NTAPS == 9) ? KDIP_B_DEPTH_SMALL : KDIP_B_DEPTH;   // stages ahead
   uint4 bq[BD + 1][KS][NT][NPB];
 
   // prologue: the first two B stages are requested together with the first patch, ahead of the LDS write + barrier
@@ -838,7 +843,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
         {
           int ntap = tap + 1, nsub = sub;
           if (ntap == NTAPS) { ntap = 0; nsub = sub + 1; }
-          if (KDIP_A_PREFETCH && nsub < SUBS) load_a(aq1, abuf, nsub, ntap);
+          if (APF && nsub < SUBS) load_a(aq1, abuf, nsub, ntap);
         }
         if (KDIP_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -869,14 +874,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
 #pragma unroll
               for (int pl = 0; pl < NPB; ++pl) bq[i][ks][nt][pl] = bq[i + 1][ks][nt][pl];
           }
-          if (KDIP_A_PREFETCH) {
+          if (APF) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
               for (int pl = 0; pl < NPA; ++pl) aq0[ks][mt][pl] = aq1[ks][mt][pl];
           }
         }
-        if (!KDIP_A_PREFETCH) {
+        if (!APF) {
           int ntap = tap + 1, nsub = sub;
           if (ntap == NTAPS) { ntap = 0; nsub = sub + 1; }
           if (nsub < SUBS) load_a(aq0, abuf, nsub, ntap);
