@@ -70,6 +70,12 @@ long kdip_unet_workspace_bytes(kdip_unet* u, int B);
 /* Counter that changes whenever the handle re-allocates a workspace arena (a call at a batch whose plan does not fit): every
  * device pointer a captured hipGraph of an earlier call baked in is dangling after that -- re-capture (kdip_amd/graphs.py). */
 long kdip_unet_workspace_generation(kdip_unet* u);
+/* KDIP_BF16X3 handles: how the dgrad convs of kdip_unet_vjp place the fp16 window of their gradient operand (gradients have no natural
+ * scale).  per_launch = 0 (default): one power-of-two scale per VJP from max |cotangent| -- right for networks whose backward gains
+ * keep the gradient tensors of one VJP within +-4 decades of the cotangent (elements outside lose their fp16 tails: the error falls
+ * back towards bf16's, never to inf).  per_launch = 1: every dgrad launch derives its scale from a sampled max of its own input (one
+ * extra ~4 us launch each, +2 % per guided call): f32-grade whatever the network's backward gains. */
+int kdip_unet_x3_window(kdip_unet* u, int per_launch);
 /* Debug / test aid: 64-bit word sum of the activation stash kdip_unet_vjp reads (unchanged between a forward and its VJPs). */
 int kdip_unet_debug_stash_checksum(kdip_unet* u, void* stream, unsigned long long* sum_host);
 

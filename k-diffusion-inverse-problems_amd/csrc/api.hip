@@ -103,6 +103,15 @@ int kdip_unet_debug_stash_checksum(kdip_unet* u, void* stream, unsigned long lon
   return KDIP_OK;
 }
 long kdip_unet_workspace_generation(kdip_unet* u) { return u ? u->u.ws_generation : -1; }
+int kdip_unet_x3_window(kdip_unet* u, int per_launch) {
+  KDIP_REQUIRE(u, "null handle");
+  KDIP_REQUIRE(u->u.cdt == DT_F32X3, "x3_window: the handle was not created with KDIP_BF16X3");
+  if (u->u.x3_window_per_launch != (per_launch ? 1 : 0)) {
+    u->u.x3_window_per_launch = per_launch ? 1 : 0;
+    u->u.planned.clear();              // the per-launch words live in the zeros arena: re-plan every batch
+  }
+  return KDIP_OK;
+}
 long kdip_unet_workspace_bytes(kdip_unet* u, int B) {
   if (!u) return -1;
   if (B > 0 && u->u.finalized) { int rc = u->u.ensure_workspace(B); if (rc) return rc; }

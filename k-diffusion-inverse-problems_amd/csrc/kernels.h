@@ -137,6 +137,8 @@ int gauss_nll_mean(hipStream_t st, const float* pred, const float* target, const
 int silu_f32(hipStream_t st, const float* x, long n, float* y);
 // *out = bits of max |x| (fp32 bit patterns of non-negative floats order like unsigned integers); capture-safe (memset + one kernel)
 int amax_bits(hipStream_t st, const float* x, long n, unsigned* out);
+// sampled variant (every k-th 16-byte vector, k chosen so that ~64 K vectors are read); *out_zeroed must be zero on entry; n % 4 == 0, x 16-byte aligned
+int amax_bits_sampled(hipStream_t st, const float* x, long n, unsigned* out_zeroed);
 int timestep_embedding(hipStream_t st, const float* t, int B, int dim, float* out);
 int f32_to_T(hipStream_t st, DType dt, const float* x, long n, void* y);
 int T_to_f32(hipStream_t st, DType dt, const void* x, long n, float* y);

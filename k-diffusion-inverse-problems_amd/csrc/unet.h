@@ -81,6 +81,7 @@ struct UNet {
   Arena persist, scratch, zeros;     // zeros: fp64 statistics accumulators, cleared once per forward / VJP
   size_t zeros_fwd_end = 0;
   unsigned* x3_amax = nullptr;       // split-precision mode: bits of max |cotangent| of the current VJP (fp16 window of the dgrad convs' A operand)
+  int x3_window_per_launch = 0;      // 1: every dgrad launch takes its window from a sampled max |g| of its own input instead (kdip_unet_x3_window)
   float* sk_ws = nullptr; long sk_ws_floats = 0;   // split-K workspace of the small-spatial convs (zeros arena; kept zero by the finalize kernel)
   std::map<std::pair<const void*, int>, double*> fused_stats;   // (tensor, channels) -> GroupNorm sums already accumulated by its producer
   int ws_B = 0;                       // largest batch planned so far

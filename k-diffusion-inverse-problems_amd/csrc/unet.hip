@@ -442,7 +442,16 @@ int conv_b(Ctx& c, const ConvW& w, const void* g, long ldg, int B, int H, int W,
   }
   if (tf2_coef) return set_error(KDIP_ERR_STATE, "internal: fused GroupNorm-backward staging requested for a conv the second-generation kernel cannot run");
   ConvStats stt;
-  stt.x3_amax = c.u->x3_amax;          // (split-precision mode) gradients have no natural scale: the window follows this VJP's cotangent
+  // (split-precision mode) gradients have no natural scale: the fp16 window of the A operand follows max |cotangent| of this VJP
+  // (one reduction per VJP) -- enough for networks whose backward gains keep the gradient tensors of one VJP within +-4 decades of
+  // it.  kdip_unet_x3_window(u, 1): every dgrad launch takes its own power-of-two scale from a sampled max |g| of its input instead
+  // (a word of the zeros arena, cleared with it at the start of the VJP; one ~4 us launch in front of each dgrad conv: +2.3 % per step)
+  stt.x3_amax = c.u->x3_amax;
+  if (c.u->x3_amax && c.u->x3_window_per_launch) {
+    unsigned* aw = (unsigned*)c.u->zeros.alloc(sizeof(unsigned));
+    RUN(amax_bits_sampled(c.st, (const float*)g, ((long)B * H * W - 1) * ldg + w.cin_pad_b, aw));      // (the span of a channel-slice view)
+    stt.x3_amax = aw;
+  }
   if (stats_ok) {
     stt.mode = 2; stt.silu = gn_silu; stt.x = gn_x; stt.ldx = gn_ldx; stt.coef = gn_coef; stt.mr = gn_mr;
     stt.sums = new_sums(c, B);
@@ -841,7 +850,7 @@ int UNet::vjp_impl(hipStream_t st, const float* cot_nchw, float* gx_nchw) {
   // cotangent NCHW fp32 [B,out_ch,H,W] -> NHWC T padded to 32 channels
   void* cot = persist.alloc(es * B * HW0 * 32);
   RUN(nchw_to_nhwc(st, dt, cot_nchw, B, cfg.out_channels, H0, W0, 1.f, cot, 32, 32));
-  if (x3_amax) RUN(amax_bits(st, cot_nchw, (long)B * cfg.out_channels * HW0, x3_amax));
+  if (x3_amax && !x3_window_per_launch) RUN(amax_bits(st, cot_nchw, (long)B * cfg.out_channels * HW0, x3_amax));
   void* ghn = scratch.alloc(es * B * HW0 * final_ch);
   double* sumsh = nullptr;
   int gh_dz = 0;

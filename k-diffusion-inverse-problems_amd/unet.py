@@ -125,6 +125,13 @@ class UNetModel:
                                            L.ptr(cov), L.ptr(feat)))
         return out, cov, feat
 
+    def set_x3_window(self, mode):
+        """dtype "bf16x3" only: "vjp" (default) = one fp16-window scale per VJP from max |cotangent|; "launch" = every dgrad conv scales
+        by a sampled max of its own input (robust to networks with very large backward gains, +2 % per call)."""
+        if mode not in ("vjp", "launch"):
+            raise ValueError("mode must be 'vjp' or 'launch'")
+        L.check(self.lib.kdip_unet_x3_window(self._h, 1 if mode == "launch" else 0))
+
     def vjp(self, cot):
         """(d out / d x_in)^T cot for the last forward; cot [B,6,S,S] -> [B,3,S,S]."""
         if not (cot.is_cuda and cot.dtype == torch.float32 and cot.device == self.device):

@@ -92,3 +92,49 @@ def test_x3_out_of_window_degrades_gracefully():
         e = float((y.double() - ref).abs().max() / ref.abs().max())
         print(f"\nx3 forward, input scale {scale:g}: max|err|/max|ref| {e:.2e}")
         assert e < bound, (scale, e)
+
+
+def test_x3_unet_with_wide_dynamic_range():
+    """The window assumptions of the split-precision mode on a network whose tensors are far from O(1): the tiny UNet with its second
+    ResBlock convs scaled x 100 (the raw residual stream that the 1x1 skip convs and the next GroupNorms read reaches the hundreds; the
+    backward gains of those convs spread the internal gradients of one VJP over many decades) and VJP cotangents of scale 1e-6 / 1 / 1e+3.
+    Forward: bf16x3 = exact-f32 to the f32 mode's own accuracy.  VJP, default window (one power-of-two scale per VJP from max |cotangent|):
+    the tails of the far-off layers fade -- the documented graceful degradation (5e-5 relative; plain bf16: 4e-2), finite, independent of
+    the cotangent's own scale.  VJP with `set_x3_window("launch")` (every dgrad launch scales by a sampled max of its own input): back at
+    1e-5 on this extreme network."""
+    import kdip_amd.unet as ku
+    from oracle import unet as ounet
+    cfg = ounet.UNetConfig(**ounet.TINY)
+    sd = {k: (v * 100.0 if ".out_layers.3.weight" in k else v) for k, v in ounet.init_state_dict(cfg, seed=0).items()}
+    kw = dict(image_size=64, model_channels=32, num_res_blocks=1, attention_resolutions="32", channel_mult=(1, 2))
+    ms = {}
+    for dt in ("f32", "bf16x3", "bf16"):
+        ms[dt] = ku.UNetModel(dtype=dt, **kw)
+        ms[dt].load_state_dict(sd)
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(2, 3, 64, 64, generator=g).cuda()
+    t = torch.tensor([100.0, 700.0]).cuda()
+    outs = {dt: m.forward_raw(x, t, want_feature=True) for dt, m in ms.items()}
+    feat = outs["f32"][2]
+    assert float(feat.abs().max()) > 100.0, float(feat.abs().max())       # the stream really is far from O(1)
+    e = float((outs["bf16x3"][0] - outs["f32"][0]).abs().max() / outs["f32"][0].abs().max())
+    print(f"\nwide-range UNet: max |feature| {float(feat.abs().max()):.0f}; forward rel-max bf16x3 vs f32 {e:.2e}")
+    assert e < 2e-5, e
+    for scale in (1e-6, 1.0, 1e3):
+        cot = (torch.randn(2, 6, 64, 64, generator=g) * scale).cuda()
+        v = {dt: m.vjp(cot) for dt, m in ms.items()}
+        v2 = ms["f32"].vjp(cot)
+        ev = float((v["bf16x3"] - v["f32"]).abs().max() / v["f32"].abs().max())
+        eb = float((v["bf16"] - v["f32"]).abs().max() / v["f32"].abs().max())
+        en = float((v2 - v["f32"]).abs().max() / v["f32"].abs().max())
+        print(f"wide-range UNet: VJP rel-max vs f32 at cotangent scale {scale:g}: bf16x3 {ev:.2e}, bf16 {eb:.2e}, f32 re-run {en:.2e}")
+        assert torch.isfinite(v["bf16x3"]).all() and ev < 5e-4 and ev < eb / 100, (scale, ev, eb)
+        ms["bf16x3"].set_x3_window("launch")
+        try:
+            ms["bf16x3"].forward_raw(x, t)
+            el = float((ms["bf16x3"].vjp(cot) - v["f32"]).abs().max() / v["f32"].abs().max())
+        finally:
+            ms["bf16x3"].set_x3_window("vjp")
+            ms["bf16x3"].forward_raw(x, t)
+        print(f"                 ... per-launch window: bf16x3 {el:.2e}")
+        assert el < 3e-5 and el < ev, (scale, el, ev)

@@ -1,2 +1,3 @@
-mkdir -p gpurun_out/r04r
-for v in "" _x3tfapf0 "" _x3tfapf0; do echo -n "[$v] "; KDIP_LIB_PATH=$GRAFT_REPO_ROOT/k-diffusion-inverse-problems_amd/libkdip_hip$v.so python bench.py --dtype bf16x3 --steps 20 --warmup 2 --no-cpu-baseline --no-large-batch --no-f32-leg --no-graph-leg 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], {k:v['tflops'] for k,v in d['roofline']['all_conv_classes'].items()})"; done > gpurun_out/r04r/ab.log 2>&1
+mkdir -p gpurun_out/r04w
+python -m pytest tests/test_x3_gpu.py tests/test_parity_gpu.py -q -m gpu -s -k "x3 or churn or sampler_golden" 2>&1 | grep -E "wide-range|per-launch|churn.*x3|passed|failed|assert|Error" | cut -c1-260 > gpurun_out/r04w/t.log
+python bench.py --dtype bf16x3 --steps 20 --warmup 2 --no-cpu-baseline --no-large-batch --no-f32-leg --no-graph-leg --no-roofline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'])" > gpurun_out/r04w/bench.log
