@@ -481,7 +481,7 @@ def main():
         # the reference at the same bounds as the exact-f32 mode (tests/test_parity_gpu.py, test_x3_gpu.py, test_fullsize_gpu.py)
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--dtype", "bf16x3", "--batch", str(B), "--streams", str(args.streams),
-                                "--steps", "20", "--warmup", "2", "--no-cpu-baseline", "--no-large-batch", "--no-f32-leg"],
+                                "--steps", str(args.steps if full_run else 20), "--warmup", "2", "--no-cpu-baseline", "--no-large-batch", "--no-f32-leg", "--no-graph-leg"],
                                capture_output=True, text=True, timeout=900)
             x3 = json.loads(r.stdout.strip().splitlines()[-1])
             x3r = x3.get("roofline", {})
@@ -494,7 +494,7 @@ def main():
                                                       "mfma_work_frac_of_peak": round(3.0 * x3r["achieved"] / BF16_MFMA_PEAK_TFLOPS, 4) if x3r.get("achieved") else None,
                                                       "all_conv_classes": x3r.get("all_conv_classes"), "hbm_bound_classes": {k: v for k, v in (x3r.get("hbm_bound_classes") or {}).items() if k.startswith("gn")},
                                                       "pmc_micro": "profiles/r04/pmc_x3_conv_micro.json (MFMA busy 0.585 at 1.81 GHz, traffic 1.11 x algorithmic)"},
-                                         "note": "same workload, protocol and code path (python bench.py --dtype bf16x3 --steps 20): fp32 activations, every conv as "
+                                         "note": "same workload, protocol and code path (python bench.py --dtype bf16x3, the full 100-step run when the main leg is one, else a 20-step subset): fp32 activations, every conv as "
                                                  "1 v_mfma_f32_32x32x16_bf16 + 2 v_mfma_f32_32x32x16_f16 per product with fp32 accumulation (conv error at the "
                                                  "exact-f32 kernel's level): the mode that meets the 1e-3 dB tolerance at speed"}
         except Exception as e:

@@ -549,7 +549,8 @@ def test_eps_mse_loss_value(tiny):
     assert float((got - ref).abs().max() / ref.abs().max()) < 2e-4, (got, ref)
 
 
-def test_hipgraph_capture_replay(gold, tiny):
+@pytest.mark.parametrize("dt", ["f32", "bf16x3"])      # (bf16x3: the cotangent-amax reduction of the VJP -- memset + kernel -- is captured too)
+def test_hipgraph_capture_replay(gold, tiny, dt):
     """Capture / replay of guided calls (kdip_amd.graphs.GraphedDenoiser): the closed-form branch is captured once per sigma into a
     hipGraph and replayed for new inputs with results equal to the eager call (fp64-atomic order noise only); with capture_cg=False
     the CG branch stays eager (it reads convergence flags back to the host; test_hipgraph_cg_branch_fixed_trips covers its capture)."""
@@ -557,7 +558,7 @@ def test_hipgraph_capture_replay(gold, tiny):
     from kdip_amd.graphs import GraphedDenoiser
     models, D, sd, cfg = tiny
     hop, oop, (y, yf), x0 = make_ops("gaussian_blur", gold)
-    den = kc.ConditionOpenAIDenoiser(inner_model=models["f32"], diffusion=D, x0_cov_type="convert", recon_mse=None, operator=hop,
+    den = kc.ConditionOpenAIDenoiser(inner_model=models[dt], diffusion=D, x0_cov_type="convert", recon_mse=None, operator=hop,
                                      measurement=(y.cuda(), yf.cuda()), guidance="I", device="cuda")     # (f32 mode: run-to-run noise is ~1e-6;
     gd = GraphedDenoiser(den, capture_cg=False)                                                          #  bf16 re-rounds the atomics-order noise to ~1e-3)
     g = torch.Generator().manual_seed(21)
