@@ -109,6 +109,7 @@ int kdip_unet_x3_window(kdip_unet* u, int per_launch) {
   if (u->u.x3_window_per_launch != (per_launch ? 1 : 0)) {
     u->u.x3_window_per_launch = per_launch ? 1 : 0;
     u->u.planned.clear();              // the per-launch words live in the zeros arena: re-plan every batch
+    u->u.have_stash = false;           // ... and a VJP needs a forward made under the new plan
   }
   return KDIP_OK;
 }
