@@ -376,7 +376,7 @@ int kdip_test_conv(void* stream, int dtype, int ntaps, const float* x_nchw, int 
   }
   if (storage_out) {     // the UNet-internal epilogues: output in the storage dtype
     KDIP_HIP_CHECK(hipMalloc(&ys, es * (size_t)B * H * W * opad));
-    const long wsf = (long)B * H * W * Co + KDIP_SK_TICKETS;   // zeroed split-K workspace (+ ticket words): under-filled shapes take the split-K path
+    const long wsf = (long)B * H * W * Co;             // zeroed split-K workspace: under-filled shapes take the split-K path
     KDIP_HIP_CHECK(hipMalloc((void**)&skws, sizeof(float) * wsf));
     KDIP_HIP_CHECK(hipMemsetAsync(skws, 0, sizeof(float) * wsf, st));
     if (!rc) rc = conv_forward(st, cdt, ntaps, xin, cpad, B, H, W, cpad, wp, bias, Co, ys, opad, nullptr, 0, 0, 1.f, 0, amax ? &stt : nullptr, skws, wsf);

@@ -132,8 +132,8 @@ struct ConvParams {
   int fast_epilogue;              // bf16 out, all strides / pointers 16-byte friendly: 8-channel-per-lane stores (below)
   int fast_epilogue32;            // fp32 storage out (f32 / split-precision modes), 16-byte friendly: epilogue_f32_fast
   float* sk_ws; long sk_ws_floats; int sk_splits;    // split-K (small-spatial layers): blockIdx.y owns a K-chunk range, fp32 partial sums are
-                                  // atomically added to sk_ws [B*H*W][Cout] (zero on entry); the LAST block to arrive at a tile (ticket counter
-  int* sk_tickets;                // sk_tickets[tile], zero on entry) adds bias / residual, casts, stores and re-zeroes its part of sk_ws: one launch
+                                  // atomically added to sk_ws [B*H*W][Cout] (zero on entry; conv_splitk_finalize re-zeroes it).  (An in-kernel
+                                  // reduction by the last block to arrive measured slower: tools/experiments/splitk_inkernel.patch)
   int in_ups, res_ups;            // input / residual are half-resolution tensors read at (y >> 1, x >> 1) (fused nearest x2 upsample)
   int persist;                    // persistent launch: blocks walk a tile range, epilogue LDS sits behind the two A buffers
   // fused GroupNorm statistics of the OUTPUT tensor (vector epilogue, one image per tile only):
@@ -217,12 +217,6 @@ constexpr int KC = 32;            // input channels per B-pipeline stage (one ta
 #endif
 #ifndef KDIP_SPLITK_FILL
 #define KDIP_SPLITK_FILL 512   // split K until a launch has about this many blocks (2 per CU)
-#endif
-#ifndef KDIP_SK_INKERNEL
-#define KDIP_SK_INKERNEL 0     // 1: split-K tiles are finished by the last block to arrive instead of a conv_splitk_finalize launch.  Measured (round 4,
-                               // 8 images): 8x8 512->512 25.0 vs 19.3 us, 16x16 512->512 42.4 vs 32.1 us, step 42.0 vs 41.1 ms -- waiting for the
-                               // atomics' acknowledgements + ticket + atomic read-back costs more than the second launch (with agent-scope fences
-                               // instead: 60.8 us).  Kept for A/B builds; the finalize launch stays the default
 #endif
 #ifndef KDIP_EARLY_WRITE
 #define KDIP_EARLY_WRITE 5
@@ -910,7 +904,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
     continue;
   }
   if (p.sk_splits > 1) {
-    // split-K partial sums: fp32 atomics into the zeroed workspace; the last block to arrive at this tile finishes it (below)
+    // split-K partial sums: fp32 atomics into the zeroed workspace; bias / residual / cast happen in conv_splitk_finalize
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int n = (nt0 + nt) * 32 + (lane & 31);
@@ -925,44 +919,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
           if (n < p.Cout && gb < p.B)
             atomicAdd(p.sk_ws + (((long)gb * p.H + (y0 + ty)) * p.W + (x0 + tx)) * p.Cout + n, acc[mt][nt][r] * alpha);
         }
-    }
-    // ---- in-kernel reduction (replaces the conv_splitk_finalize launch: the 8x8 / 16x16 conv + finalize pairs were a fixed ~19 us
-    // latency chain).  All traffic on the workspace and the ticket goes through device-scope ATOMICS, which execute at the one
-    // coherence point of the chip (beyond the per-XCD L2s: the partial sums of a tile come from blocks on different XCDs) -- no
-    // agent-scope fence, whose L2 write-back + invalidate per block measured 3 x slower than the separate finalize launch.  A
-    // block waits until its own atomics are acknowledged (workgroup-scope release = s_waitcnt vmcnt(0)), then one thread draws a
-    // ticket; the block that draws the last one reads-and-zeroes the sums with atomic exchanges and writes the tile: bias +
-    // residual + cast; the ticket goes back to zero for the next launch.
-    if (!KDIP_SK_INKERNEL) { KDIP_STAMP(3); continue; }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    int* slast = (int*)smem;                             // (the A buffers are dead)
-    if (tid == 0) *slast = __hip_atomic_fetch_add(p.sk_tickets + bid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.sk_splits - 1;
-    __syncthreads();
-    if (*slast) {
-      using ST = std::conditional_t<X3, float, T>;       // storage type
-      const ST* resS = (const ST*)p.res;
-      ST* yS = (ST*)p.y;
-      constexpr int V4 = BN / 4;
-      for (int idx = tid; idx < BM * V4; idx += NTHREADS) {
-        const int m = idx / V4, n = ntb * BN + (idx - m * V4) * 4;
-        const int tb = m >> p.lgTHW, rr = m & ((1 << p.lgTHW) - 1);
-        const int ty = rr >> p.lgTW, tx = rr & (p.TW - 1);
-        const int gb = img0 + tb;
-        if (gb >= p.B || n >= p.Cout) continue;          // (Cout % 4 == 0 on this path)
-        const long pix = ((long)gb * p.H + (y0 + ty)) * p.W + (x0 + tx);
-        float* w4 = p.sk_ws + pix * p.Cout + n;
-        float f[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) f[e] = __hip_atomic_exchange(w4 + e, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (p.bias) f[e] += p.bias[n + e];
-          if (resS) f[e] += to_f32(resS[pix * p.ldr + n + e]);
-          yS[pix * p.ldy + n + e] = from_f32<ST>(f[e]);
-        }
-      }
-      if (tid == 0) __hip_atomic_store(p.sk_tickets + bid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     KDIP_STAMP(3);
     continue;
@@ -1273,16 +1229,14 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
   {
     const int nchunks = p.Cin / (KC * SUBS);
     // (3x3 only: on the short-K 1x1 convs the atomics + finalize pass cost more than the extra blocks bring, measured)
-    if (KDIP_SPLITK && NTAPS == 9 && p.sk_ws && (long)p.B * p.H * p.W * p.Cout <= p.sk_ws_floats - KDIP_SK_TICKETS && grid <= KDIP_SK_TICKETS && !p.persist && !p.st_mode && !p.out_f32 && !p.res_ups && p.Cout % 4 == 0 && grid * 2 <= KDIP_SPLITK_FILL && nchunks >= 4) {
+    if (KDIP_SPLITK && NTAPS == 9 && p.sk_ws && (long)p.B * p.H * p.W * p.Cout <= p.sk_ws_floats && !p.persist && !p.st_mode && !p.out_f32 && !p.res_ups && p.Cout % 4 == 0 && grid * 2 <= KDIP_SPLITK_FILL && nchunks >= 4) {
       splits = (int)(KDIP_SPLITK_FILL / grid);
       if (splits > nchunks / KDIP_SPLITK_MINCH) splits = nchunks / KDIP_SPLITK_MINCH;
       if (splits > KDIP_SPLITK_MAX) splits = KDIP_SPLITK_MAX;
     }
   }
   p.sk_splits = splits;
-  p.sk_tickets = p.sk_ws ? (int*)(p.sk_ws + (p.sk_ws_floats - KDIP_SK_TICKETS)) : nullptr;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)splits), dim3(WAVES_M * WAVES_N * 64), lds, st, p);
-#if !KDIP_SK_INKERNEL
   if (splits > 1) {
     const long npix = (long)p.B * p.H * p.W;
     long g = (npix * (p.Cout / 4) + 255) / 256; if (g > 4096) g = 4096;
@@ -1290,7 +1244,6 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
     hipLaunchKernelGGL(conv_splitk_finalize_kernel<ST>, dim3((unsigned)g), dim3(256), 0, st, p.sk_ws, p.bias, (const ST*)p.res, p.ldr, npix, p.Cout,
                        (ST*)p.y, p.ldy);
   }
-#endif
   prof_end(st);
   KDIP_LAUNCH_CHECK();
   return KDIP_OK;

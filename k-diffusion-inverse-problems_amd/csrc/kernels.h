@@ -27,8 +27,7 @@ inline bool conv_stats_eligible(int H, int W, int Cout) { return (long)H * W >= 
 int conv_forward(hipStream_t st, DType dt, int ntaps, const void* x, long ldx, int B, int H, int W, int Cin,
                  const void* wp, const float* bias, int Cout, void* y, long ldy, const void* res, long ldr,
                  int out_f32, float alpha, int cin_real = 0, const ConvStats* stt = nullptr, float* sk_ws = nullptr, long sk_ws_floats = 0);
-constexpr int KDIP_SK_TICKETS = 2048;     // the last KDIP_SK_TICKETS words of a split-K workspace are the per-tile arrival counters
-// sk_ws: optional fp32 split-K workspace of sk_ws_floats floats (incl. the ticket words), all zero on entry and on return; when given, under-filled
+// sk_ws: optional fp32 split-K workspace of sk_ws_floats floats, all zero on entry and on return; when given, under-filled
 // launches (small-spatial layers) split their K range over blockIdx.y and reduce through it
 size_t packed_weight_bytes(DType dt, int ntaps, int Cin_pad, int Cout);
 int conv_debug_timing(void* buf, int H, int cin, int cout, int st_mode);   // -DKDIP_TIMING=1 diagnostic builds only

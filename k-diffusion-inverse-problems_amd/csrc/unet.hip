@@ -628,7 +628,7 @@ int UNet::forward_impl(hipStream_t st, const float* x_nchw, const float* t, int 
     for (auto& b : inp) upd(b);
     upd(mid);
     for (auto& b : out) upd(b);
-    sk_ws_floats = (long)B * 256 * maxc + KDIP_SK_TICKETS;
+    sk_ws_floats = (long)B * 256 * maxc;
     sk_ws = (float*)zeros.alloc(sizeof(float) * sk_ws_floats);
   }
   int H = cfg.image_size, W = cfg.image_size;
