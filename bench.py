@@ -17,8 +17,14 @@ timed region.  value = images/s of the whole job = N * batch / (100 * seconds_pe
 Extra objects on the JSON line:
   roofline     dominant kernel (bf16 3x3 implicit-GEMM conv): algorithmic FLOPs / HIP-event time,
                measured live in an extra profiled pass after the timed region
+               (+ hbm_bound_classes: GroupNorm / operator / point-wise kernels in GB/s; op_bandwidth_at_64_images)
   cpu_baseline the CPU oracle (torch-CPU fp32 restatement of the reference, oracle/) timed on the
-               host cores on a bounded sample (rank 0, N = 1 only)
+               host cores on a bounded sample (rank 0, N = 1 only); reference_cross_check = the imported
+               reference vs the oracle at equal cores (profiles/r04/ref_vs_oracle_cpu.json)
+  bf16x3_parity_mode / f32_parity_mode   the same workload in the two arithmetic modes that meet the 1e-3 dB
+               tolerance against the reference's fp32 arithmetic (split-precision convs / exact-f32 MFMA)
+  hipgraph_replay, throughput_at_batch_128   extra legs (N = 1)
+  ranks, distinct_devices, backend, gather_ms   multi-GPU evidence (one process per GPU, RCCL all_gather at the end)
 """
 import argparse
 import ctypes as C
