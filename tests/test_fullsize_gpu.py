@@ -349,11 +349,12 @@ def test_baseline_config_shapes_run(cid, cfg, opn, guid, cov, extra, ortho, samp
     assert float(out.abs().max()) < 5.0
 
 
-def test_unet_vjp_properties_fullsize():
-    """Size-independent properties of the hand-written input-VJP at full size (FFHQ, f32 mode, batch 2):
+@pytest.mark.parametrize("dt", ["f32", "bf16x3"])
+def test_unet_vjp_properties_fullsize(dt):
+    """Size-independent properties of the hand-written input-VJP at full size (FFHQ, f32 and bf16x3 modes, batch 2):
     linearity in the cotangent, and <c, J v> from a central finite difference of the forward == <J^T c, v> (checked over repeated runs: the forward has fp64-atomic-order noise ~1e-7)."""
     import kdip_amd.unet as ku
-    m = ku.UNetModel(dtype="f32", **ku.FFHQ_CONFIG)
+    m = ku.UNetModel(dtype=dt, **ku.FFHQ_CONFIG)
     m.load_state_dict(ku.synthetic_state_dict(seed=0, **ku.FFHQ_CONFIG))
     g = torch.Generator().manual_seed(9)
     x = (0.7 * smooth_image(2, 256, 4) + 0.3 * torch.randn(2, 3, 256, 256, generator=g)).cuda()
@@ -372,7 +373,7 @@ def test_unet_vjp_properties_fullsize():
     m.forward(x, t)
     rhs = (m.vjp(c1).double() * v.double()).flatten(1).sum(1)              # <J^T c, v>
     rel = float(((lhs - rhs).abs() / rhs.abs().clamp_min(1e-6)).max())
-    print(f"\nVJP linearity {lin:.1e}; directional derivative rel err {rel:.2e} (lhs {lhs.tolist()}, rhs {rhs.tolist()})")
+    print(f"\n{dt}: VJP linearity {lin:.1e}; directional derivative rel err {rel:.2e} (lhs {lhs.tolist()}, rhs {rhs.tolist()})")
     assert rel < 5e-3, (lhs, rhs)
 
 
