@@ -129,6 +129,20 @@ def test_imagenet_motion_typeI_analytic_fullsize(sigma_v):
     err = float((hat - ref).abs().max())
     del m, hm
     torch.cuda.empty_cache()
+    m3 = ku.UNetModel(dtype="bf16x3", **ku.IMAGENET_CONFIG); m3.load_state_dict(sd)
+    hm3 = kc.ConditionOpenAIDenoiser(inner_model=m3, diffusion=D, x0_cov_type="analytic", recon_mse=rmd, operator=hop,
+                                     measurement=measd, guidance="I", device="cuda")
+    hat3 = hm3(x.cuda(), torch.full((2,), sigma_v, device="cuda")).cpu()
+    # (its own borderline pixels: the oracle is given THIS run's clamp mask, as for the f32 run above)
+    oden.clamp_mask_override = hm3._stash[0].cpu().abs() <= 1
+    ref3 = oden(x, torch.full((2,), sigma_v))
+    flips3 = (oden.last_x0_raw.abs() <= 1) != oden.clamp_mask_override
+    assert int(flips3.sum()) <= 4 and (not flips3.any() or float((oden.last_x0_raw[flips3].abs() - 1).abs().max()) < 1e-4)
+    err3 = float((hat3 - ref3).abs().max())
+    print(f"\nconfigs[3] sigma={sigma_v}: bf16x3 max-abs {err3:.2e} ({int(flips3.sum())} borderline clamp pixels)")
+    assert err3 < 2e-3, err3                 # the split-precision mode at the f32 bound
+    del m3, hm3
+    torch.cuda.empty_cache()
     m2 = ku.UNetModel(dtype="bf16", **ku.IMAGENET_CONFIG); m2.load_state_dict(sd)
     hm2 = kc.ConditionOpenAIDenoiser(inner_model=m2, diffusion=D, x0_cov_type="analytic", recon_mse=rmd, operator=hop,
                                      measurement=measd, guidance="I", device="cuda")
