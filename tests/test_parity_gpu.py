@@ -256,8 +256,10 @@ def test_v2_dwt_autoI_vs_oracle(gold, tiny):
         assert float((hat - ref).abs().max()) < 3e-3, sigma_v
 
 
-def test_batch_semantics(gold, tiny):
-    """B independent problems: a batch of 3 equals three batch-1 calls (f32 mode)."""
+@pytest.mark.parametrize("dt", ["f32", "bf16x3"])
+def test_batch_semantics(gold, tiny, dt):
+    """B independent problems: a batch of 3 equals three batch-1 calls (f32 and bf16x3 modes; in bf16x3 the batch also changes the
+    per-VJP fp16 window -- max |cotangent| runs over the whole batch -- which must not matter at this accuracy)."""
     import kdip_amd.condition as kc
     models, D, sd, cfg = tiny
     hop, oop, (y, yf), x0 = make_ops("gaussian_blur", gold)
@@ -265,11 +267,11 @@ def test_batch_semantics(gold, tiny):
     ys = (y + 0.05 * torch.randn(3, 3, 64, 64, generator=g)).cuda()
     xs = (x0 + 0.12 * torch.randn(3, 3, 64, 64, generator=g)).cuda()
     sig = torch.full((3,), 0.12, device="cuda")
-    m = kc.ConditionOpenAIDenoiser(inner_model=models["f32"], diffusion=D, x0_cov_type="convert", recon_mse=None,
+    m = kc.ConditionOpenAIDenoiser(inner_model=models[dt], diffusion=D, x0_cov_type="convert", recon_mse=None,
                                    operator=hop, measurement=(ys, ys.flatten(1)), guidance="I", device="cuda")
     full = m(xs, sig)
     for b in range(3):
-        mb = kc.ConditionOpenAIDenoiser(inner_model=models["f32"], diffusion=D, x0_cov_type="convert", recon_mse=None,
+        mb = kc.ConditionOpenAIDenoiser(inner_model=models[dt], diffusion=D, x0_cov_type="convert", recon_mse=None,
                                         operator=hop, measurement=(ys[b:b + 1], ys[b:b + 1].flatten(1)), guidance="I", device="cuda")
         one = mb(xs[b:b + 1], sig[:1])
         assert float((one - full[b:b + 1]).abs().max()) < 2e-4
