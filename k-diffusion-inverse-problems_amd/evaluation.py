@@ -65,7 +65,7 @@ class DistEnv:
             for attr in ("pci_bus_id", "uuid"):
                 v = getattr(p, attr, None)
                 if v is not None and str(v) not in ("", "0"):
-                    ident = f"{attr}:{v}" + (f".{getattr(p, 'pci_device_id', '')}" if attr == "pci_bus_id" else "")
+                    ident = (f"pci:{getattr(p, 'pci_domain_id', 0)}:{v}:{getattr(p, 'pci_device_id', 0)}" if attr == "pci_bus_id" else f"{attr}:{v}")
                     break
             if ident is None:
                 ident = f"index:{self.device.index}"
