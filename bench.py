@@ -1,11 +1,14 @@
 #!/usr/bin/env python
 """Benchmark of the hot path: BASELINE.json configs[1] -- FFHQ 256x256 Gaussian deblur, Type-I
 guidance with Convert posterior covariance, 100 Heun steps, batch 16 per MI355X (--batch) run as
---streams (2) independent part-batches on their own HIP streams / host threads.  At N = 1 the same run is
+--streams (2) independent part-batches on their own HIP streams / host threads.  The headline runs in the bf16x3 arithmetic
+(fp32 storage, split-precision convs, deterministic reductions): the fast mode that meets north_star's 1e-3 dB against the
+reference's fp32 arithmetic; the bf16 throughput mode and the exact-f32 mode are carried as extra legs.  At N = 1 the same run is
 repeated at batch 128 and reported as `throughput_at_batch_128` (per-image cost falls with batch).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  (N > 1: either under a launcher -- python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ... -- or
+   plainly as `python bench.py --gpus N`, which starts the N ranks itself)
 
 A "step" is one Heun sampler step of the 100-step Karras schedule over one batch of 16 synthetic
 images (2 guided-denoiser calls = 2 UNet forwards + 2 hand-written UNet VJPs + 2 mat-solves, CG
@@ -21,8 +24,8 @@ Extra objects on the JSON line:
   cpu_baseline the CPU oracle (torch-CPU fp32 restatement of the reference, oracle/) timed on the
                host cores on a bounded sample (rank 0, N = 1 only); reference_cross_check = the imported
                reference vs the oracle at equal cores (profiles/r04/ref_vs_oracle_cpu.json)
-  bf16x3_parity_mode / f32_parity_mode   the same workload in the two arithmetic modes that meet the 1e-3 dB
-               tolerance against the reference's fp32 arithmetic (split-precision convs / exact-f32 MFMA)
+  bf16_throughput_mode / f32_parity_mode   the same workload in the other two arithmetic modes (bf16: faster, narrower than the
+               reference, NOT the headline; f32: exact-f32 MFMA)
   hipgraph_replay, throughput_at_batch_128   extra legs (N = 1)
   ranks, distinct_devices, backend, gather_ms   multi-GPU evidence (one process per GPU, RCCL all_gather at the end)
 """
@@ -179,6 +182,20 @@ class PowerSampler:
         return out
 
 
+def self_launch(n):
+    """Re-run this command line as n ranks: python -m torch.distributed.run --nnodes=1 --nproc-per-node n --master-addr 127.0.0.1
+    --master-port <free port> bench.py <same arguments>.  stdout / stderr are inherited, the exit code is the launcher's."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -188,13 +205,21 @@ def main():
     ap.add_argument("--no-large-batch", action="store_true", help="skip the extra throughput leg at batch 128 (N = 1 only)")
     ap.add_argument("--streams", type=int, default=2, help="part-batches per GPU, each on its own HIP stream + host thread")
     ap.add_argument("--cu-split", action="store_true", help="give each part-batch stream its own share of the compute units (CU-masked HIP streams)")
-    ap.add_argument("--dtype", choices=("bf16", "f32", "bf16x3"), default="bf16",
-                    help="UNet storage / MFMA type (f32 = the exact-f32 parity mode; bf16x3 = fp32 storage + split-bf16 convs, the fast tolerance-compliant mode)")
+    ap.add_argument("--dtype", choices=("bf16", "f32", "bf16x3"), default="bf16x3",
+                    help="UNet arithmetic: bf16x3 (default) = fp32 storage + split-precision convs, the fast mode that meets north_star's 1e-3 dB against the "
+                         "reference's fp32 arithmetic; f32 = exact-f32 MFMA; bf16 = the throughput mode (narrower than the reference: reported beside the headline, never as it)")
     ap.add_argument("--no-graph-leg", action="store_true", help="skip the extra leg that replays the guided calls from hipGraphs (N = 1 only)")
-    ap.add_argument("--no-f32-leg", action="store_true", help="skip the extra leg that times the same workload in the f32 parity mode (N = 1 only)")
+    ap.add_argument("--no-f32-leg", action="store_true", help="skip the extra legs that time the same workload in the other two arithmetic modes (N = 1 only)")
+    ap.add_argument("--topology-only", action="store_true", help="start the ranks, report {ranks, distinct_devices, backend, devices} as one JSON line and exit "
+                                                                  "(no GPU work: also runs on a CPU-only host, where the ranks rendezvous over gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): start the N ranks ourselves, one process per
+    # GPU under torch.distributed.run on the loopback address, pass the arguments through and relay rank 0's JSON line.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     import kdip_amd._lib as L
     import kdip_amd.unet as ku
@@ -204,7 +229,14 @@ def main():
     from kdip_amd.evaluation import DistEnv
 
     env = DistEnv()
-    assert env.world_size == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={env.world_size}"
+    if env.world_size != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env.world_size} (run `python bench.py --gpus N` on its own, or under a launcher with matching --nproc-per-node)")
+    if args.topology_only:
+        topo = env.topology()
+        if env.is_main_process:
+            print(json.dumps({"n_gpus": args.gpus, **topo}))
+        env.barrier()
+        return
     L.require_gpu()
     dev = env.device
     B, S, rank = args.batch, 256, env.rank
@@ -374,7 +406,12 @@ def main():
             op_big = {"error": repr(e)[:200]}
         # dominant kernel = the (kernel class, layer shape) with the largest total time in the profiled pass
         import csv, tempfile, collections
-        dump = os.environ.get("KDIP_PROFILE_DUMP") or os.path.join(tempfile.gettempdir(), f"kdip_conv_dump_{os.getpid()}.csv")
+        dump = os.environ.get("KDIP_PROFILE_DUMP")
+        if dump:                            # one file per arithmetic mode: the sub-legs below run this script again with the same environment
+            root_, ext_ = os.path.splitext(dump)
+            dump = f"{root_}.{args.dtype}{ext_ or '.csv'}"
+        else:
+            dump = os.path.join(tempfile.gettempdir(), f"kdip_conv_dump_{os.getpid()}.csv")
         L.check(lib.kdip_profile_dump(dump.encode()))
         grp = collections.defaultdict(lambda: [0, 0.0, 0.0, 0.0])
         for r in csv.DictReader(open(dump)):
@@ -387,7 +424,8 @@ def main():
         # HBM traffic of this (kernel, fusion mode, layer shape): rocprofv3 --pmc passes over the same in-network launches
         # (tools/pmc_innetwork.sh -> profiles/r04_pmc_innetwork.json; FETCH_SIZE x 2 + WRITE_SIZE per MI355X_MICROARCH.md)
         traffic, traffic_source, pmc_extra = None, None, {}
-        pmc = next((f for f in (os.path.join(ROOT, "profiles", t + "_pmc_innetwork.json") for t in ("r04", "r03", "r02")) if os.path.exists(f)), "")
+        cands = ["r05_pmc_innetwork_" + args.dtype] + (["r05_pmc_innetwork", "r04_pmc_innetwork", "r03_pmc_innetwork", "r02_pmc_innetwork"] if args.dtype == "bf16" else [])
+        pmc = next((f for f in (os.path.join(ROOT, "profiles", t + ".json") for t in cands) if os.path.exists(f)), "")
         if pmc:
             try:
                 e = json.load(open(pmc))["shapes"].get("|".join(key[1:]))
@@ -411,7 +449,11 @@ def main():
             "kernel": f"{key[1]} ({'conv3_kernel, csrc/conv3.hip' if key[1].startswith('conv3') else 'conv_igemm_kernel, csrc/conv.hip'}, v_mfma_f32_32x32x16_bf16: {desc}), "
                       f"layer B={key[2]} {key[4]}->{key[5]} ch @ {key[3]}x{key[3]}",
             "bound": "mfma", "achieved": round(tflops, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(tflops / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source, "pmc_in_network": pmc_extra,
+            "frac": round(tflops / BF16_MFMA_PEAK_TFLOPS, 4),
+            # `achieved` counts ALGORITHMIC flops (one multiply-add per MAC).  The split-precision mode issues three 16-bit MFMAs
+            # per product (the exact-f32 mode: the 8x slower fp32 MFMA), so the matrix pipes are busier than `frac` says by this factor:
+            "mfma_instructions_per_product": {"bf16x3": 3, "bf16": 1, "f32": 1}[args.dtype],
+            "mfma_work_frac_of_peak": round({"bf16x3": 3.0, "bf16": 1.0, "f32": 1.0}[args.dtype] * tflops / BF16_MFMA_PEAK_TFLOPS, 4) if args.dtype != "f32" else None, "traffic": traffic, "traffic_source": traffic_source, "pmc_in_network": pmc_extra,
             "launches": cnt, "avg_launch_us": round(us / cnt, 2), "algorithmic_gflop_per_launch": round(gf / cnt, 3),
             "algorithmic_bytes_per_launch": round(mb / cnt * 1e6),
             "share_of_profiled_conv_time": round(us / max(sum(v[1] for v in grp.values()), 1e-9), 3),
@@ -439,7 +481,7 @@ def main():
     # ---- extra leg (N = 1): the same timed steps with every closed-form guided call replayed from a hipGraph captured once per
     # (sigma, part-batch) -- what a server that runs this schedule for batch after batch does (kdip_amd/graphs.py); the CG-branch
     # calls stay eager.  Captures happen in an untimed pass, sequentially per part.
-    if not args.no_graph_leg and env.world_size == 1 and args.dtype == "bf16":
+    if not args.no_graph_leg and env.world_size == 1 and args.dtype != "f32":
         try:
             from kdip_amd.graphs import GraphedDenoiser
             for pt in parts:
@@ -469,8 +511,8 @@ def main():
         del parts, den, x0
         torch.cuda.empty_cache()
         try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--batch", "128", "--streams", str(args.streams), "--steps", str(args.steps),
-                                "--warmup", "2", "--no-cpu-baseline", "--no-roofline", "--no-large-batch", "--no-f32-leg"], capture_output=True, text=True, timeout=900)
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--dtype", args.dtype, "--batch", "128", "--streams", str(args.streams), "--steps", str(args.steps),
+                                "--warmup", "2", "--no-cpu-baseline", "--no-roofline", "--no-large-batch", "--no-f32-leg", "--no-graph-leg"], capture_output=True, text=True, timeout=1500)
             big = json.loads(r.stdout.strip().splitlines()[-1])
             out["throughput_at_batch_128"] = {"value": big["value"], "unit": "images/s", "per_gpu_batch": 128,
                                               "streams_per_gpu": big["config"]["streams_per_gpu"], "ms_per_step": big["ms_per_step"],
@@ -478,44 +520,48 @@ def main():
         except Exception as e:            # the headline measurement above must survive a failure of the optional leg
             out["throughput_at_batch_128"] = {"error": repr(e)[:200]}
 
-    # ---- extra leg (N = 1): the SAME workload in the f32 parity mode (fp32 activations, exact-f32 MFMA) -- the arithmetic
-    # that meets the 1e-3 dB tolerance against the reference (tests/test_parity_gpu.py); `value` above is the bf16 mode, whose
-    # end-to-end PSNR deviation from this mode is measured by tests/test_fullsize_gpu.py::test_e2e_bf16_vs_f32_psnr.
-    if not args.no_f32_leg and env.world_size == 1 and args.dtype == "bf16" and B == 16:
+    # ---- extra legs (N = 1): the SAME workload, protocol and code path in the other two arithmetic modes, each as a fresh process.
+    # `value` is the bf16x3 mode (fp32 storage, split-precision convs: the fast mode that meets the 1e-3 dB tolerance against the
+    # reference's fp32 arithmetic, tests/test_parity_gpu.py / test_x3_gpu.py / test_fullsize_gpu.py); bf16 is the throughput mode --
+    # narrower than the reference (utils_model.py:364 use_fp16=False), reported beside the headline, never as it; f32 = exact-f32 MFMA.
+    if not args.no_f32_leg and env.world_size == 1 and B == 16:
         import subprocess
-        # the FAST tolerance-compliant mode: fp32 storage + split-precision convs (bf16 head + fp16 tails, 3 MFMAs per product), pinned to
-        # the reference at the same bounds as the exact-f32 mode (tests/test_parity_gpu.py, test_x3_gpu.py, test_fullsize_gpu.py)
-        try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--dtype", "bf16x3", "--batch", str(B), "--streams", str(args.streams),
-                                "--steps", str(args.steps if full_run else 20), "--warmup", "2", "--no-cpu-baseline", "--no-large-batch", "--no-f32-leg", "--no-graph-leg"],
-                               capture_output=True, text=True, timeout=900)
-            x3 = json.loads(r.stdout.strip().splitlines()[-1])
-            x3r = x3.get("roofline", {})
-            out["bf16x3_parity_mode"] = {"value": x3["value"], "unit": "images/s", "dtype": "bf16x3", "ms_per_step": x3["ms_per_step"], "steps": x3["steps"],
-                                         "bf16_over_bf16x3": round(images_per_s / x3["value"], 2),
-                                         "achieved_tflops_whole_step": x3["achieved_tflops_whole_step"],
-                                         # dominant kernel of THIS mode, measured live like `roofline` above: algorithmic TFLOP/s (one product per MAC) and the
-                                         # MFMA work it stands for (three 16-bit MFMAs per product) against the 2.5 PFLOP/s dense peak
-                                         "roofline": {"kernel": x3r.get("kernel"), "achieved": x3r.get("achieved"), "unit": "TFLOP/s", "avg_launch_us": x3r.get("avg_launch_us"),
-                                                      "mfma_work_frac_of_peak": round(3.0 * x3r["achieved"] / BF16_MFMA_PEAK_TFLOPS, 4) if x3r.get("achieved") else None,
-                                                      "all_conv_classes": x3r.get("all_conv_classes"), "hbm_bound_classes": {k: v for k, v in (x3r.get("hbm_bound_classes") or {}).items() if k.startswith("gn")},
-                                                      "pmc_micro": "profiles/r04/pmc_x3_conv_micro.json (MFMA busy 0.585 at 1.81 GHz, traffic 1.11 x algorithmic)"},
-                                         "note": "same workload, protocol and code path (python bench.py --dtype bf16x3, the full 100-step run when the main leg is one, else a 20-step subset): fp32 activations, every conv as "
-                                                 "1 v_mfma_f32_32x32x16_bf16 + 2 v_mfma_f32_32x32x16_f16 per product with fp32 accumulation (conv error at the "
-                                                 "exact-f32 kernel's level): the mode that meets the 1e-3 dB tolerance at speed"}
-        except Exception as e:
-            out["bf16x3_parity_mode"] = {"error": repr(e)[:200]}
-        try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--dtype", "f32", "--batch", str(B), "--streams", str(args.streams),
-                                "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-roofline", "--no-large-batch", "--no-f32-leg"],
-                               capture_output=True, text=True, timeout=900)
-            f32 = json.loads(r.stdout.strip().splitlines()[-1])
-            out["f32_parity_mode"] = {"value": f32["value"], "unit": "images/s", "dtype": "f32", "ms_per_step": f32["ms_per_step"], "steps": f32["steps"],
-                                      "bf16_over_f32": round(images_per_s / f32["value"], 2),
-                                      "note": "same workload, protocol and code path (python bench.py --dtype f32 --steps 4): fp32 activations + "
-                                              "v_mfma_f32_32x32x2_f32, the mode pinned to the reference within 1e-3 dB PSNR"}
-        except Exception as e:
-            out["f32_parity_mode"] = {"error": repr(e)[:200]}
+
+        def sub_leg(dtype, steps, flags):
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--dtype", dtype, "--batch", str(B), "--streams", str(args.streams), "--steps", str(steps),
+                                "--warmup", "2", "--no-cpu-baseline", "--no-large-batch", "--no-f32-leg"] + flags, capture_output=True, text=True, timeout=900)
+            return json.loads(r.stdout.strip().splitlines()[-1])
+
+        def leg_roofline(rf, per_product):
+            if not rf:
+                return None
+            return {"kernel": rf.get("kernel"), "achieved": rf.get("achieved"), "unit": "TFLOP/s", "frac": rf.get("frac"), "avg_launch_us": rf.get("avg_launch_us"),
+                    "mfma_work_frac_of_peak": round(per_product * rf["achieved"] / BF16_MFMA_PEAK_TFLOPS, 4) if rf.get("achieved") else None,
+                    "all_conv_classes": rf.get("all_conv_classes"),
+                    "hbm_bound_classes": {k: v for k, v in (rf.get("hbm_bound_classes") or {}).items() if k.startswith("gn")}}
+        others = [d for d in ("bf16x3", "bf16", "f32") if d != args.dtype]
+        for d in others:
+            name = {"bf16x3": "bf16x3_parity_mode", "bf16": "bf16_throughput_mode", "f32": "f32_parity_mode"}[d]
+            try:
+                if d == "f32":
+                    leg = sub_leg("f32", 4, ["--no-roofline", "--no-graph-leg"])
+                else:
+                    leg = sub_leg(d, args.steps if full_run else 20, [] if d == "bf16" else ["--no-graph-leg"])
+                o = {"value": leg["value"], "unit": "images/s", "dtype": d, "ms_per_step": leg["ms_per_step"], "steps": leg["steps"],
+                     "over_headline": round(leg["value"] / images_per_s, 3), "achieved_tflops_whole_step": leg["achieved_tflops_whole_step"]}
+                if d != "f32":
+                    o["roofline"] = leg_roofline(leg.get("roofline"), 3.0 if d == "bf16x3" else 1.0)
+                if d == "bf16":
+                    o["hipgraph_replay"] = leg.get("hipgraph_replay")
+                    o["note"] = ("same workload, protocol and code path (python bench.py --dtype bf16): bf16 activations and MFMA inputs -- NOT tolerance-compliant (|dPSNR| ~1e-2 dB "
+                                 "against the f32 arithmetic end to end, per-call PSNR floors in tests/test_fullsize_gpu.py::test_e2e_teacher_forced); a throughput figure, not the headline")
+                elif d == "f32":
+                    o["note"] = "same workload, protocol and code path (python bench.py --dtype f32 --steps 4): fp32 activations + v_mfma_f32_32x32x2_f32, the reference's own arithmetic"
+                else:
+                    o["note"] = "same workload, protocol and code path (python bench.py --dtype bf16x3): fp32 activations, every conv as 1 bf16 + 2 fp16 MFMAs per product, fp32 accumulation"
+                out[name] = o
+            except Exception as e:
+                out[name] = {"error": repr(e)[:200]}
 
     # ---- CPU baseline (rank 0, single-GPU runs only; bounded sample)
     if not args.no_cpu_baseline and env.is_main_process and env.world_size == 1:

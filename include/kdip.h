@@ -28,9 +28,14 @@ extern "C" {
 enum { KDIP_OK = 0, KDIP_ERR_ARG = -1, KDIP_ERR_HIP = -2, KDIP_ERR_STATE = -3, KDIP_ERR_NOMEM = -4,
        KDIP_ERR_UNSUPPORTED = -5 };
 enum { KDIP_F32 = 0, KDIP_BF16 = 1,                   /* storage / MFMA input type of the UNet */
-       KDIP_BF16X3 = 2 };   /* fp32 storage, split-precision convs: operands = bf16 hi + bf16 lo, hi*hi + hi*lo + lo*hi on the bf16
-                             * MFMA with fp32 accumulation (operand error ~2^-17 instead of 2^-9): the fast mode that meets the
-                             * 1e-3 dB tolerance against the reference's fp32 arithmetic (utils_model.py:364 use_fp16=False) */
+       KDIP_BF16X3 = 2 };   /* fp32 storage, split-precision convs: every product a*b as three 16-bit MFMAs into one fp32 accumulator --
+                             * bf16(a)*bf16(b) + f16(a)*f16(b - bf16(b)) + f16(a - bf16(a))*f16(bf16(b)) (bf16 head, fp16 tails with
+                             * power-of-two range scaling; csrc/conv.hip Mma<f32x3_t>): operand error ~2^-21 of the tensor's scale instead
+                             * of bf16's 2^-9 -- the fast mode that meets the 1e-3 dB tolerance against the reference's fp32 arithmetic
+                             * (utils_model.py:364 use_fp16=False).
+                             * KDIP_F32 and KDIP_BF16X3 handles are DETERMINISTIC: every cross-block reduction (GroupNorm statistics,
+                             * split-K partial sums) is made in a fixed order (csrc/det.h), two runs of one call are bitwise equal, as
+                             * the reference's CPU path is.  KDIP_BF16 (throughput mode) uses floating-point atomics. */
 enum { KDIP_OP_INPAINT = 0, KDIP_OP_BLUR = 1, KDIP_OP_SR = 2 };
 enum { KDIP_OT_NONE = 0, KDIP_OT_DWT = 1, KDIP_OT_DCT = 2 };
 
@@ -76,6 +81,9 @@ long kdip_unet_workspace_generation(kdip_unet* u);
  * back towards bf16's, never to inf).  per_launch = 1: every dgrad launch derives its scale from a sampled max of its own input (one
  * extra ~4 us launch each, +2 % per guided call): f32-grade whatever the network's backward gains. */
 int kdip_unet_x3_window(kdip_unet* u, int per_launch);
+/* (no reference counterpart) A/B switch of the fixed-order reductions of a KDIP_F32 / KDIP_BF16X3 handle (default on; off = the
+ * floating-point atomics of the KDIP_BF16 mode: measures what reproducibility costs).  Returns the previous setting (0 | 1) or < 0. */
+int kdip_unet_deterministic(kdip_unet* u, int on);
 /* Debug / test aid: 64-bit word sum of the activation stash kdip_unet_vjp reads (unchanged between a forward and its VJPs). */
 int kdip_unet_debug_stash_checksum(kdip_unet* u, void* stream, unsigned long long* sum_host);
 

@@ -47,6 +47,7 @@ int kdip_unet_create(int device, int dtype, int image_size, int in_channels, int
   h->u.device = device;
   h->u.dt = dtype == KDIP_BF16 ? DT_BF16 : DT_F32;
   h->u.cdt = dtype == KDIP_BF16X3 ? DT_F32X3 : h->u.dt;
+  h->u.det = dtype != KDIP_BF16;        // fp32-storage modes: fixed-order reductions (det.h)
   h->u.cfg.image_size = image_size; h->u.cfg.in_channels = in_channels; h->u.cfg.model_channels = model_channels;
   h->u.cfg.out_channels = out_channels; h->u.cfg.num_res_blocks = num_res_blocks;
   h->u.cfg.attention_ds.assign(attention_ds, attention_ds + n_attention_ds);
@@ -110,8 +111,21 @@ int kdip_unet_x3_window(kdip_unet* u, int per_launch) {
     u->u.x3_window_per_launch = per_launch ? 1 : 0;
     u->u.planned.clear();              // the per-launch words live in the zeros arena: re-plan every batch
     u->u.have_stash = false;           // ... and a VJP needs a forward made under the new plan
+    ++u->u.ws_generation;              // graphs captured under the other window mode replay its kernels / arena offsets: invalidate them (graphs.py keys on this)
   }
   return KDIP_OK;
+}
+int kdip_unet_deterministic(kdip_unet* u, int on) {
+  KDIP_REQUIRE(u, "null handle");
+  KDIP_REQUIRE(u->u.dt != DT_BF16 || !on, "deterministic reductions are instantiated for the fp32-storage modes (KDIP_F32, KDIP_BF16X3) only");
+  const int prev = u->u.det ? 1 : 0;
+  if (prev != (on ? 1 : 0)) {
+    u->u.det = on != 0;
+    u->u.planned.clear();              // slabs / counters / split-K workspace move between arenas: re-plan every batch
+    u->u.have_stash = false;
+    ++u->u.ws_generation;              // captured hipGraphs replay the old mode's kernels and offsets: invalidate them
+  }
+  return prev;
 }
 long kdip_unet_workspace_bytes(kdip_unet* u, int B) {
   if (!u) return -1;

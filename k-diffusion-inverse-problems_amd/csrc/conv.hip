@@ -27,6 +27,7 @@
 #include <stdlib.h>
 #include "common.h"
 #include "kernels.h"
+#include "det.h"
 
 namespace kdip {
 
@@ -147,6 +148,9 @@ struct ConvParams {
   const float* st_mr;             // mode 2: [B][32][2] (mean, rstd)
   const float* tf_coef; int tf_silu;   // split precision, 3x3: the input is a GroupNorm INPUT; silu?(a*x + b) with (a, b) = tf_coef[B][Cin][2] is applied while
                                   // the patch is staged (conv zero padding applies to the transformed tensor); one image per tile only
+  float* det_slab; unsigned* det_cnt; size_t det_slab_bytes; int det_ncnt;   // deterministic modes (det.h): fused statistics go block by block into det_slab [B][tiles per image][n-blocks][BN/4][2] and are
+                                  // added in slot order by the last block of each image (counter det_cnt[image]); split-K partials go to per-split slabs of sk_ws (sk_det)
+  int sk_det;
   const unsigned* x3_amax;        // split precision: optional device word = bits of max |x| of the input's tensor family (sets the fp16 window of the A operand)
   unsigned long long* dbg;        // KDIP_TIMING builds: [grid][8] s_memrealtime stamps (start, staged, k-loop done, end, store loop done, sync 1, sync 2)
 };
@@ -251,6 +255,76 @@ constexpr int KC = 32;            // input channels per B-pipeline stage (one ta
                              // +4 - 6 % over 1 on the large maps; the 1x1 instantiations keep 1 (-6 % with 2)
 #endif
 
+
+// ---- block-level combine + hand-over of the fused GroupNorm sums (fp32-storage and generic epilogues) -------------------------
+// Every wave holds (s1, s2) of its 4-channel vectors (lanes < LPR after the row reduction).  Waves sharing a channel range (same wn)
+// park their pairs in their own LDS rows and thread v adds the WAVES_M rows in order (no LDS atomics: with four row waves their
+// arrival order would change the rounding).  Then either one fp64 atomic pair per vector (bf16 throughput mode), or -- deterministic
+// modes -- the pair goes to this block's slot of the slab and the last block of the image adds all slots in order (det.h).
+template <int WAVES_M, int BN, int LPR>
+__device__ __forceinline__ void conv_stats_handover(const ConvParams& p, float s1, float s2, float* sred, int tid, int lane, int wm, int wn, int ntb,
+                                                    int nblkN, int img0, int trem, int tpi) {
+  const int cpg = p.Cout >> 5;
+  __syncthreads();                                  // all waves past their use of the transpose regions
+  if (lane < LPR) {
+    sred[((wm * (BN / 4)) + wn * LPR + lane) * 2] = s1;
+    sred[((wm * (BN / 4)) + wn * LPR + lane) * 2 + 1] = s2;
+  }
+  __syncthreads();
+  float a = 0.f, q = 0.f;
+  if (tid < BN / 4) {
+#pragma unroll
+    for (int w = 0; w < WAVES_M; ++w) { a += sred[(w * (BN / 4) + tid) * 2]; q += sred[(w * (BN / 4) + tid) * 2 + 1]; }
+  }
+  const int n = ntb * BN + tid * 4;
+  const bool live = tid < BN / 4 && n < p.Cout && img0 < p.B;
+  if (!p.det_slab) {
+    if (live) {
+      double* dst = p.st_sums + ((long)img0 * 32 + n / cpg) * 2;
+#if !KDIP_ABL_NOATOM
+      atomicAdd(dst, (double)a);
+      atomicAdd(dst + 1, (double)q);
+#else
+      if (a == 12345.678f) dst[0] = q;
+#endif
+    }
+    return;
+  }
+  // slot of (image, tile, n-block, vector): [img][trem][ntb][BN/4][2]
+  float* slab = p.det_slab + ((long)img0 * tpi) * nblkN * (BN / 4) * 2;
+  if (tid < BN / 4) {
+    float* slot = slab + (((long)trem * nblkN + ntb) * (BN / 4) + tid) * 2;
+    det_store(slot, live ? a : 0.f);
+    det_store(slot + 1, live ? q : 0.f);
+  }
+  if (!det_last_block(p.det_cnt + img0, (unsigned)(tpi * nblkN))) return;
+  // last block of image img0: thread (group g = tid >> 3, segment sg = tid & 7) adds the group's vectors over its range of tiles in
+  // order (fp64); the 8 segments of a group are then added in order.  256 threads (every tile configuration has 4 waves).
+  double* dsh = (double*)sred;                      // [32][8][2] doubles = 4 KiB (the transpose regions in front are dead)
+  {
+    const int g = tid >> 3, sg = tid & 7;
+    const int t0 = (int)((long)tpi * sg / 8), t1 = (int)((long)tpi * (sg + 1) / 8);
+    const int v0 = g * cpg / 4, v1 = (g + 1) * cpg / 4;        // cpg % 4 == 0 (launch precondition of the fused statistics)
+    double da = 0.0, dq = 0.0;
+    for (int t = t0; t < t1; ++t)
+      for (int v = v0; v < v1; ++v) {
+        const float* slot = slab + (((long)t * nblkN + v / (BN / 4)) * (BN / 4) + v % (BN / 4)) * 2;
+        da += (double)det_load(slot);
+        dq += (double)det_load(slot + 1);
+      }
+    __syncthreads();                                // (sred reads above are done in every thread)
+    dsh[(g * 8 + sg) * 2] = da;
+    dsh[(g * 8 + sg) * 2 + 1] = dq;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int g = tid >> 1, k = tid & 1;
+    double r = 0.0;
+#pragma unroll
+    for (int sg = 0; sg < 8; ++sg) r += dsh[(g * 8 + sg) * 2 + k];
+    p.st_sums[((long)img0 * 32 + g) * 2 + k] = r;
+  }
+}
 
 // ---- bf16 fast epilogue ------------------------------------------------------------------
 // One code path per (residual, statistics mode), no branches inside: the wave transposes its fp32
@@ -421,7 +495,7 @@ __device__ __forceinline__ void epilogue_bf16_fast(const ConvParams& p, f32x16 (
 // while the exact-f32 MFMAs were the bottleneck, it does for the 5 x shorter K loop of the split-precision mode.)
 template <int WAVES_M, int WAVES_N, int MT, int NT, bool RES, int MODE>
 __device__ __forceinline__ void epilogue_f32_fast(const ConvParams& p, f32x16 (&acc)[MT][NT], float alpha, unsigned char* smem, int tid, int lane, int wave,
-                                                  int wm, int wn, int nt0, int ntb, int img0, int y0, int x0) {
+                                                  int wm, int wn, int nt0, int ntb, int img0, int y0, int x0, int nblkN, int trem, int tpi) {
   constexpr int BN = WAVES_N * NT * 32;
   constexpr int RS = NT * 32 * 4 + 16;               // fp32 row stride of the per-wave region
   constexpr int LPR = NT * 8;                        // lanes (4-channel vectors) per pixel row
@@ -436,9 +510,6 @@ __device__ __forceinline__ void epilogue_f32_fast(const ConvParams& p, f32x16 (&
   const float* sx = (const float*)p.st_x;
   float* yout = (float*)p.y;
   float s1 = 0.f, s2 = 0.f;
-  if (MODE) {
-    if (tid < BN / 4 * 2) sred[tid] = 0.f;
-  }
   float bv[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) bv[nt] = p.bias ? p.bias[(nt0 + nt) * 32 + (lane & 31)] : 0.f;
@@ -513,22 +584,12 @@ __device__ __forceinline__ void epilogue_f32_fast(const ConvParams& p, f32x16 (&
     }
   }
   if (MODE) {
-    // rows -> lanes sharing `vec`; then waves -> LDS; then one fp64 atomic pair per 4-channel vector
+    // rows -> lanes sharing `vec` (xor butterfly: the same additions in every run), then the block-level combine
 #pragma unroll
     for (int o = LPR; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-    __syncthreads();                                  // sred zeroed, all waves past their creg use
-    if (lane < LPR) {
-      atomicAdd(&sred[(wn * LPR + lane) * 2], s1);
-      atomicAdd(&sred[(wn * LPR + lane) * 2 + 1], s2);
-    }
-    __syncthreads();
-    if (tid < BN / 4) {
-      const int n = ntb * BN + tid * 4;
-      double* dst = p.st_sums + ((long)img0 * 32 + n / cpg) * 2;
-      atomicAdd(dst, (double)sred[tid * 2]);
-      atomicAdd(dst + 1, (double)sred[tid * 2 + 1]);
-    }
+    conv_stats_handover<WAVES_M, BN, LPR>(p, s1, s2, sred, tid, lane, wm, wn, ntb, nblkN, img0, trem, tpi);
   }
+  (void)cpg;
 }
 
 // SUBS = 32-channel sub-chunks staged in LDS per barrier (1 for 3x3; up to 4 for 1x1 so a barrier
@@ -916,8 +977,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
           const int tb = m >> p.lgTHW, rr = m & ((1 << p.lgTHW) - 1);
           const int ty = rr >> p.lgTW, tx = rr & (p.TW - 1);
           const int gb = img0 + tb;
-          if (n < p.Cout && gb < p.B)
-            atomicAdd(p.sk_ws + (((long)gb * p.H + (y0 + ty)) * p.W + (x0 + tx)) * p.Cout + n, acc[mt][nt][r] * alpha);
+          if (n < p.Cout && gb < p.B) {
+            float* dst = p.sk_ws + (((long)gb * p.H + (y0 + ty)) * p.W + (x0 + tx)) * p.Cout + n;
+            if (p.sk_det) dst[(long)blockIdx.y * p.B * p.H * p.W * p.Cout] = acc[mt][nt][r] * alpha;      // this split's own slab: summed in split order by the finalize pass
+            else atomicAdd(dst, acc[mt][nt][r] * alpha);
+          }
         }
     }
     KDIP_STAMP(3);
@@ -939,7 +1003,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
   }
   if constexpr (sizeof(T) == 4) {
     if (KDIP_FAST_EPI32 && p.fast_epilogue32 && (ntb + 1) * BN <= p.Cout) {     // block-uniform
-#define KDIP_EPI32(R, M) epilogue_f32_fast<WAVES_M, WAVES_N, MT, NT, R, M>(p, acc, alpha, smem, tid, lane, wave, wm, wn, nt0, ntb, img0, y0, x0)
+#define KDIP_EPI32(R, M) epilogue_f32_fast<WAVES_M, WAVES_N, MT, NT, R, M>(p, acc, alpha, smem, tid, lane, wave, wm, wn, nt0, ntb, img0, y0, x0, nblkN, trem, tpi)
       if (p.res) {
         if (p.st_mode == 0) KDIP_EPI32(true, 0); else if (p.st_mode == 1) KDIP_EPI32(true, 1); else KDIP_EPI32(true, 2);
       } else {
@@ -966,7 +1030,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
     float s1 = 0.f, s2 = 0.f;
     float ca[4] = {0, 0, 0, 0}, cb[4] = {0, 0, 0, 0}, gmean = 0.f, grstd = 0.f;
     if (p.st_mode) {
-      if (tid < BN / 4 * 2) sred[tid] = 0.f;
       if (p.st_mode == 2 && nl < p.Cout && img0 < p.B) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1050,30 +1113,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
     }
     KDIP_STAMP(4);
     if (p.st_mode) {
-      // rows -> lanes sharing `vec`; then waves -> LDS; then one fp64 atomic pair per 4-channel vector
+      // rows -> lanes sharing `vec` (xor butterfly), then the block-level combine
 #pragma unroll
       for (int o = LPR; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-      __syncthreads();                                  // sred zeroed, all waves past their creg use
       KDIP_STAMP(5);
-      if (lane < LPR) {
-        atomicAdd(&sred[(wn * LPR + lane) * 2], s1);
-        atomicAdd(&sred[(wn * LPR + lane) * 2 + 1], s2);
-      }
-      __syncthreads();
+      conv_stats_handover<WAVES_M, BN, LPR>(p, s1, s2, sred, tid, lane, wm, wn, ntb, nblkN, img0, trem, tpi);
       KDIP_STAMP(6);
-      if (tid < BN / 4) {
-        const int n = ntb * BN + tid * 4;
-        if (n < p.Cout && img0 < p.B) {
-          double* dst = p.st_sums + ((long)img0 * 32 + n / cpg) * 2;
-#if !KDIP_ABL_NOATOM
-          atomicAdd(dst, (double)sred[tid * 2]);
-          atomicAdd(dst + 1, (double)sred[tid * 2 + 1]);
-#else
-          if (sred[tid * 2] == 12345.678f) dst[0] = sred[tid * 2 + 1];
-#endif
-        }
-      }
     }
+    (void)cpg;
     KDIP_STAMP(3);
     continue;
   }
@@ -1107,15 +1154,24 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
 }
 
 // y = T(ws + bias (+ res)); ws is zeroed again for the next split-K launch
+// det_splits > 0 (deterministic modes): ws holds det_splits slabs [npix][Cout] of plain partial sums, added here in split order;
+// nothing is re-zeroed
 template <typename T>
 __global__ void conv_splitk_finalize_kernel(float* __restrict__ ws, const float* __restrict__ bias, const T* __restrict__ res, long ldr,
-                                            long npix, int Cout, T* __restrict__ y, long ldy) {
+                                            long npix, int Cout, T* __restrict__ y, long ldy, int det_splits) {
   const long n4 = (long)Cout / 4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix * n4; i += (long)gridDim.x * blockDim.x) {
     const long pix = i / n4;
     const int c = (int)(i % n4) * 4;
     float4 v = *(float4*)(ws + pix * Cout + c);
-    *(float4*)(ws + pix * Cout + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (det_splits > 0) {
+      for (int sp = 1; sp < det_splits; ++sp) {
+        const float4 w = *(const float4*)(ws + (long)sp * npix * Cout + pix * Cout + c);
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+      }
+    } else {
+      *(float4*)(ws + pix * Cout + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     float f[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -1160,7 +1216,10 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
   p.vec_epilogue = (p.Cout % 4 == 0) && (p.ldy % 4 == 0) && (!p.res || p.ldr % 4 == 0) &&
                    ((uintptr_t)p.y % (osz4 ? 16 : 8) == 0) && (!p.res || (uintptr_t)p.res % (sizeof(T) == 2 ? 8 : 16) == 0);
   if (p.vec_epilogue) {
-    size_t cl = (size_t)WAVES_M * WAVES_N * 32 * (NT * 32 * 4 + 16) + (size_t)BN / 4 * 2 * sizeof(float);
+    // transpose regions + the statistics exchange: [WAVES_M][BN/4][2] floats, re-used as [32][8][2] doubles by the deterministic final sum
+    size_t xs = (size_t)WAVES_M * (BN / 4) * 2 * sizeof(float);
+    if (xs < 32 * 8 * 2 * sizeof(double)) xs = 32 * 8 * 2 * sizeof(double);
+    size_t cl = (size_t)WAVES_M * WAVES_N * 32 * (NT * 32 * 4 + 16) + xs;
     if (cl > lds) lds = cl;
   }
   p.fast_epilogue = KDIP_FAST_EPI && sizeof(T) == 2 && !p.out_f32 && p.vec_epilogue && p.Cout % 8 == 0 && p.ldy % 8 == 0 && (uintptr_t)p.y % 16 == 0 &&
@@ -1229,20 +1288,24 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
   {
     const int nchunks = p.Cin / (KC * SUBS);
     // (3x3 only: on the short-K 1x1 convs the atomics + finalize pass cost more than the extra blocks bring, measured)
-    if (KDIP_SPLITK && NTAPS == 9 && p.sk_ws && (long)p.B * p.H * p.W * p.Cout <= p.sk_ws_floats && !p.persist && !p.st_mode && !p.out_f32 && !p.res_ups && p.Cout % 4 == 0 && grid * 2 <= KDIP_SPLITK_FILL && nchunks >= 4) {
+    if (KDIP_SPLITK && NTAPS == 9 && p.sk_ws && (long)p.B * p.H * p.W * p.Cout * (p.sk_det ? KDIP_SPLITK_MAX : 1) <= p.sk_ws_floats && !p.persist && !p.st_mode && !p.out_f32 && !p.res_ups && p.Cout % 4 == 0 && grid * 2 <= KDIP_SPLITK_FILL && nchunks >= 4) {
       splits = (int)(KDIP_SPLITK_FILL / grid);
       if (splits > nchunks / KDIP_SPLITK_MINCH) splits = nchunks / KDIP_SPLITK_MINCH;
       if (splits > KDIP_SPLITK_MAX) splits = KDIP_SPLITK_MAX;
     }
   }
   p.sk_splits = splits;
+  if (p.st_mode && p.det_slab) {
+    KDIP_REQUIRE(p.det_cnt && (size_t)p.mtiles * nblkN * (BN / 4) * 2 * sizeof(float) <= p.det_slab_bytes && p.B <= p.det_ncnt,
+                 "conv: deterministic-statistics workspace too small (%d tiles x %d n-blocks)", p.mtiles, nblkN);
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)splits), dim3(WAVES_M * WAVES_N * 64), lds, st, p);
   if (splits > 1) {
     const long npix = (long)p.B * p.H * p.W;
     long g = (npix * (p.Cout / 4) + 255) / 256; if (g > 4096) g = 4096;
     using ST = std::conditional_t<std::is_same<T, f32x3_t>::value, float, T>;      // storage type
     hipLaunchKernelGGL(conv_splitk_finalize_kernel<ST>, dim3((unsigned)g), dim3(256), 0, st, p.sk_ws, p.bias, (const ST*)p.res, p.ldr, npix, p.Cout,
-                       (ST*)p.y, p.ldy);
+                       (ST*)p.y, p.ldy, p.sk_det ? splits : 0);
   }
   prof_end(st);
   KDIP_LAUNCH_CHECK();
@@ -1311,6 +1374,9 @@ int conv_forward(hipStream_t st, DType dt, int ntaps, const void* x, long ldx, i
   p.st_mode = 0; p.st_silu = 0; p.st_sums = nullptr; p.st_x = nullptr; p.st_ldx = 0; p.st_coef = nullptr; p.st_mr = nullptr;
   p.in_ups = stt ? stt->in_ups : 0; p.res_ups = stt ? stt->res_ups : 0;
   p.x3_amax = stt ? stt->x3_amax : nullptr;
+  const DetWs* det = stt ? stt->det : nullptr;
+  p.det_slab = det ? (float*)det->slab : nullptr; p.det_cnt = det ? det->cnt : nullptr; p.det_slab_bytes = det ? det->slab_bytes : 0; p.det_ncnt = det ? det->ncnt : 0;
+  p.sk_det = stt ? stt->sk_det : 0;
   p.tf_coef = stt ? stt->tf_coef : nullptr; p.tf_silu = stt ? stt->tf_silu : 0;
   KDIP_REQUIRE(!p.tf_coef || (dt == DT_F32X3 && ntaps == 9 && (long)H * W >= 128 && ((uintptr_t)p.tf_coef % 16) == 0),
                "conv: fused GroupNorm staging needs the split-precision 3x3 kernel and one image per tile");

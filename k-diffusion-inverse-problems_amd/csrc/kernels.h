@@ -1,6 +1,7 @@
 // Internal C++ launch API shared by the translation units of libkdip_hip.
 #pragma once
 #include "common.h"
+#include "det.h"
 
 namespace kdip {
 
@@ -20,6 +21,10 @@ struct ConvStats {
   // split-precision 3x3 convs on maps with >= 128 pixels: the input is a GroupNorm INPUT and silu?(a*x + b), (a, b) = tf_coef [B][Cin][2]
   // (gn_coef), is applied while the patch is staged -- the activated tensor never exists in HBM (as Conv3Fuse::tf 1 does for bf16)
   const float* tf_coef = nullptr; int tf_silu = 0;
+  // deterministic modes (det.h): fused statistics reduced in a fixed order through det->slab (counters det->cnt[image]); sk_det:
+  // sk_ws is NOT pre-zeroed and holds one slab [B*H*W][Cout] per K split (sk_ws_floats bounds the number of splits), summed in
+  // split order by the finalize pass
+  const DetWs* det = nullptr; int sk_det = 0;
 };
 inline bool conv_tf_eligible(DType cdt, int ntaps, int H, int W, int Cin_pad) { return cdt == DT_F32X3 && ntaps == 9 && (long)H * W >= 128 && Cin_pad % 32 == 0; }
 // true iff conv_forward can fuse statistics for an output of this shape
@@ -91,7 +96,8 @@ int attn_fused_backward(hipStream_t st, const void* qkv, long ld, const void* dO
 
 // ---- norm.hip ---------------------------------------------------------------------------
 // GroupNorm(32) over NHWC [B, HW, C] (ld = channel stride). stats: double [B][32][2] (sum, sumsq), zeroed by callee.
-int gn_stats(hipStream_t st, DType dt, const void* x, long ldx, int B, long HW, int C, double* stats, int prezeroed = 0);
+int gn_stats(hipStream_t st, DType dt, const void* x, long ldx, int B, long HW, int C, double* stats, int prezeroed = 0, const DetWs* det = nullptr);
+// det (fp32 storage only): the sums are reduced in a fixed order through det->slab and WRITTEN (det.h) -- run-to-run bit-reproducible
 // coef[B][C][2] = (a, b) with y = a*x + b  [then SiLU]; a = rstd*gamma*(1+scale), b = (beta - mean*rstd*gamma)*(1+scale)+shift
 // film: [B][2C] fp32 (scale | shift) or null.  Also writes mr[B][32][2] = (mean, rstd) fp32.
 int gn_coef(hipStream_t st, const double* stats, const float* gamma, const float* beta, const float* film,
@@ -100,7 +106,7 @@ int gn_apply(hipStream_t st, DType dt, const void* x, long ldx, const float* coe
              void* y, long ldy);
 // backward: dy wrt apply output -> dx (+ optional addend), two passes.
 int gn_bwd_stats(hipStream_t st, DType dt, const void* x, long ldx, const void* dy, long lddy, const float* coef,
-                 const float* mr, int B, long HW, int C, int silu, double* sums, int prezeroed = 0, int half_lgW = -1);
+                 const float* mr, int B, long HW, int C, int silu, double* sums, int prezeroed = 0, int half_lgW = -1, const DetWs* det = nullptr);
 int gn_bwd_apply(hipStream_t st, DType dt, const void* x, long ldx, const void* dy, long lddy, const float* coef,
                  const float* mr, const double* sums, int B, long HW, int C, int silu, const void* addend, long lda,
                  void* dx, long lddx, const void* addend2 = nullptr, long lda2 = 0, int half_lgW = -1);

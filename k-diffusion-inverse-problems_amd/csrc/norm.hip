@@ -8,6 +8,7 @@
 // group per block) so the E[x^2]-mean^2 form has no visible cancellation.
 #include "common.h"
 #include "kernels.h"
+#include "det.h"
 
 namespace kdip {
 
@@ -28,19 +29,54 @@ template <typename T> static GnGeom gn_geom(int C) {
 }
 
 // ---------------------------------------------------------------- forward statistics ----
-template <typename T>
+// Fixed-order combine of per-thread partial sums (deterministic modes): every thread parks its EPV (sum 1, sum 2) pairs in LDS as
+// [pixel lane][channel][2]; thread (group g, k) then adds group g's lanes x cpg values in index order (fp64) -- block-size and
+// arrival-order independent.  The block's 64 results go to slot blockIdx.x of image b's slab row; the last block of the image adds
+// the slots in order and WRITES the image's statistics (det.h).
+template <int EPV>
+__device__ __forceinline__ void gn_det_combine(const float (&v1)[EPV], const float (&v2)[EPV], bool active, int vi, int pl, int lanes, int C,
+                                               int cpg, float* lsh, double* slab, unsigned* cnt, double* __restrict__ out) {
+  const int tid = threadIdx.x, b = blockIdx.y;
+  if (active) {
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+      lsh[((long)pl * C + vi * EPV + e) * 2] = v1[e];
+      lsh[((long)pl * C + vi * EPV + e) * 2 + 1] = v2[e];
+    }
+  }
+  __syncthreads();
+  double* row = slab + ((long)b * gridDim.x + blockIdx.x) * 64;
+  if (tid < 64) {
+    const int g = tid >> 1, k = tid & 1;
+    double a = 0.0;
+    for (int l = 0; l < lanes; ++l)
+      for (int c = g * cpg; c < (g + 1) * cpg; ++c) a += (double)lsh[((long)l * C + c) * 2 + k];
+    det_store(row + tid, a);
+  }
+  if (det_last_block(cnt + b, gridDim.x)) {
+    if (tid < 64) {
+      double a = 0.0;
+      const double* r0 = slab + (long)b * gridDim.x * 64 + tid;
+      for (unsigned j = 0; j < gridDim.x; ++j) a += det_load(r0 + (long)j * 64);
+      out[(long)b * 64 + tid] = a;
+    }
+  }
+}
+
+template <typename T, bool DET>
 __global__ void gn_stats_kernel(const T* __restrict__ x, long ldx, long HW, int C, int VP, int lanes, int cpg,
-                                long chunk, double* __restrict__ stats) {
+                                long chunk, double* __restrict__ stats, double* det_slab, unsigned* det_cnt) {
   constexpr int EPV = TypeInfo<T>::EPV;
   __shared__ double sh[32][2];
+  extern __shared__ __attribute__((aligned(16))) float gn_lsh[];      // DET: [lanes][C][2]
   const int tid = threadIdx.x, b = blockIdx.y;
   if (tid < 64) sh[tid >> 1][tid & 1] = 0.0;
   __syncthreads();
   const int vi = tid % VP, pl = tid / VP;
-  if (pl < lanes) {
-    float s[EPV], ss[EPV];
+  float s[EPV], ss[EPV];
 #pragma unroll
-    for (int e = 0; e < EPV; ++e) s[e] = ss[e] = 0.f;
+  for (int e = 0; e < EPV; ++e) s[e] = ss[e] = 0.f;
+  if (pl < lanes) {
     long p0 = (long)blockIdx.x * chunk, p1 = p0 + chunk < HW ? p0 + chunk : HW;
     const T* base = x + ((long)b * HW) * ldx + (long)vi * EPV;
     for (long p = p0 + pl; p < p1; p += lanes) {
@@ -50,7 +86,8 @@ __global__ void gn_stats_kernel(const T* __restrict__ x, long ldx, long HW, int 
 #pragma unroll
       for (int e = 0; e < EPV; ++e) { s[e] += f[e]; ss[e] += f[e] * f[e]; }
     }
-    if (cpg % EPV == 0) {
+    if (DET) {
+    } else if (cpg % EPV == 0) {
       float a = 0.f, q = 0.f;
 #pragma unroll
       for (int e = 0; e < EPV; ++e) { a += s[e]; q += ss[e]; }
@@ -66,6 +103,10 @@ __global__ void gn_stats_kernel(const T* __restrict__ x, long ldx, long HW, int 
       }
     }
   }
+  if (DET) {       // (block-uniform)
+    gn_det_combine<EPV>(s, ss, pl < lanes, vi, pl, lanes, C, cpg, gn_lsh, det_slab, det_cnt, stats);
+    return;
+  }
   __syncthreads();
   if (tid < 64) atomicAdd(&stats[((long)b * 32 + (tid >> 1)) * 2 + (tid & 1)], sh[tid >> 1][tid & 1]);
 }
@@ -78,22 +119,37 @@ static long pick_chunk(long HW, int B) {
   return chunk;
 }
 
-int gn_stats(hipStream_t st, DType dt, const void* x, long ldx, int B, long HW, int C, double* stats, int prezeroed) {
+// DetWs given (deterministic modes): fixed-order reduction through det->slab ([B][chunks][64] doubles), statistics WRITTEN by the
+// last block of each image (no pre-zeroing needed)
+static int gn_det_check(const DetWs* det, int B, unsigned chunks) {
+  KDIP_REQUIRE(det->slab && det->cnt && det->ncnt >= B && (size_t)B * chunks * 64 * sizeof(double) <= det->slab_bytes,
+               "groupnorm: deterministic-reduction workspace too small (%d images x %u chunks, slab %zu bytes, %d counters)", B, chunks, det->slab_bytes, det->ncnt);
+  return KDIP_OK;
+}
+int gn_stats(hipStream_t st, DType dt, const void* x, long ldx, int B, long HW, int C, double* stats, int prezeroed, const DetWs* det) {
   KDIP_REQUIRE(C % 32 == 0, "groupnorm: C=%d not a multiple of 32", C);
-  if (!prezeroed) KDIP_HIP_CHECK(hipMemsetAsync(stats, 0, sizeof(double) * B * 64, st));
+  if (!prezeroed && !det) KDIP_HIP_CHECK(hipMemsetAsync(stats, 0, sizeof(double) * B * 64, st));
   long chunk = pick_chunk(HW, B);
   dim3 grid(cdiv(HW, chunk), B);
+  if (det) {
+    KDIP_REQUIRE(dt != DT_BF16, "groupnorm: the deterministic reduction is instantiated for fp32 storage only");
+    if (int rc = gn_det_check(det, B, grid.x)) return rc;
+  }
   prof_begin(st, PC_GN_STATS, 0, (double)B * HW * C * (dt == DT_BF16 ? 2.0 : 4.0), "gn", B, HW, C, 0);
   if (dt == DT_BF16) {
     KDIP_REQUIRE(C % 8 == 0 && C / 8 <= 1024, "groupnorm: unsupported C=%d", C);
     GnGeom g = gn_geom<bf16_t>(C);
-    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(g.nthreads), 0, st, (const bf16_t*)x, ldx, HW, C, g.VP,
-                       g.lanes, g.cpg, chunk, stats);
+    hipLaunchKernelGGL((gn_stats_kernel<bf16_t, false>), grid, dim3(g.nthreads), 0, st, (const bf16_t*)x, ldx, HW, C, g.VP,
+                       g.lanes, g.cpg, chunk, stats, nullptr, nullptr);
   } else {
     KDIP_REQUIRE(C / 4 <= 1024, "groupnorm: unsupported C=%d", C);
     GnGeom g = gn_geom<float>(C);
-    hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(g.nthreads), 0, st, (const float*)x, ldx, HW, C, g.VP,
-                       g.lanes, g.cpg, chunk, stats);
+    if (det)
+      hipLaunchKernelGGL((gn_stats_kernel<float, true>), grid, dim3(g.nthreads), (size_t)g.lanes * C * 2 * sizeof(float), st, (const float*)x, ldx, HW, C, g.VP,
+                         g.lanes, g.cpg, chunk, stats, (double*)det->slab, det->cnt);
+    else
+      hipLaunchKernelGGL((gn_stats_kernel<float, false>), grid, dim3(g.nthreads), 0, st, (const float*)x, ldx, HW, C, g.VP,
+                         g.lanes, g.cpg, chunk, stats, nullptr, nullptr);
   }
   prof_end(st);
   KDIP_LAUNCH_CHECK();
@@ -278,11 +334,12 @@ int gn_apply_pool2(hipStream_t st, DType dt, const void* x, long ldx, const floa
 // --------------------------------------------------------------------------- backward ----
 // z = a*x + b, y = silu(z) | z.  dz = dy*silu'(z) | dy.  xh = (x-mean)*rstd.
 // T1 = sum_g a*dz, T2 = sum_g a*dz*xh;   dx = a*dz - T1/N - xh*T2/N   (N = HW*cpg)
-template <typename T>
+template <typename T, bool DET>
 __global__ void gn_bwd_stats_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy, long lddy,
                                     const float* __restrict__ coef, const float* __restrict__ mr, long HW, int C,
                                     int VP, int lanes, int cpg, long chunk, int silu, double* __restrict__ sums,
-                                    int half_lgW) {
+                                    int half_lgW, double* det_slab, unsigned* det_cnt) {
+  extern __shared__ __attribute__((aligned(16))) float gn_lsh[];      // DET: [lanes][C][2]
   // half_lgW >= 0: dy is a half-resolution tensor (adjoint of the 2x2 average pool, unet.py:236-240 backward):
   // dy(p) = 0.25 * dy_half[(y >> 1, x >> 1)], W = 1 << half_lgW, dy batch stride HW / 4
   constexpr int EPV = TypeInfo<T>::EPV;
@@ -291,12 +348,14 @@ __global__ void gn_bwd_stats_kernel(const T* __restrict__ x, long ldx, const T* 
   if (tid < 64) sh[tid >> 1][tid & 1] = 0.0;
   __syncthreads();
   const int vi = tid % VP, pl = tid / VP;
+  float t1[EPV], t2[EPV];
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) t1[e] = t2[e] = 0.f;
   if (pl < lanes) {
-    float t1[EPV], t2[EPV], a[EPV], bb[EPV], mean[EPV], rstd[EPV];
+    float a[EPV], bb[EPV], mean[EPV], rstd[EPV];
 #pragma unroll
     for (int e = 0; e < EPV; ++e) {
       int c = vi * EPV + e, g = c / cpg;
-      t1[e] = t2[e] = 0.f;
       a[e] = coef[((long)b * C + c) * 2];
       bb[e] = coef[((long)b * C + c) * 2 + 1];
       mean[e] = mr[((long)b * 32 + g) * 2];
@@ -320,31 +379,45 @@ __global__ void gn_bwd_stats_kernel(const T* __restrict__ x, long ldx, const T* 
         t2[e] += adz * (fx[e] - mean[e]) * rstd[e];
       }
     }
+    if (!DET) {
 #pragma unroll
-    for (int e = 0; e < EPV; ++e) {
-      int g = (vi * EPV + e) / cpg;
-      atomicAdd(&sh[g][0], (double)t1[e]);
-      atomicAdd(&sh[g][1], (double)t2[e]);
+      for (int e = 0; e < EPV; ++e) {
+        int g = (vi * EPV + e) / cpg;
+        atomicAdd(&sh[g][0], (double)t1[e]);
+        atomicAdd(&sh[g][1], (double)t2[e]);
+      }
     }
+  }
+  if (DET) {       // (block-uniform)
+    gn_det_combine<EPV>(t1, t2, pl < lanes, vi, pl, lanes, C, cpg, gn_lsh, det_slab, det_cnt, sums);
+    return;
   }
   __syncthreads();
   if (tid < 64) atomicAdd(&sums[((long)b * 32 + (tid >> 1)) * 2 + (tid & 1)], sh[tid >> 1][tid & 1]);
 }
 
 int gn_bwd_stats(hipStream_t st, DType dt, const void* x, long ldx, const void* dy, long lddy, const float* coef,
-                 const float* mr, int B, long HW, int C, int silu, double* sums, int prezeroed, int half_lgW) {
-  if (!prezeroed) KDIP_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * B * 64, st));
+                 const float* mr, int B, long HW, int C, int silu, double* sums, int prezeroed, int half_lgW, const DetWs* det) {
+  if (!prezeroed && !det) KDIP_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * B * 64, st));
   long chunk = pick_chunk(HW, B);
   dim3 grid(cdiv(HW, chunk), B);
+  if (det) {
+    KDIP_REQUIRE(dt != DT_BF16, "groupnorm: the deterministic reduction is instantiated for fp32 storage only");
+    if (int rc = gn_det_check(det, B, grid.x)) return rc;
+  }
   prof_begin(st, PC_GN_BWD_STATS, 0, 2.0 * B * HW * C * (dt == DT_BF16 ? 2.0 : 4.0), "gn", B, HW, C, 0);
   if (dt == DT_BF16) {
     GnGeom g = gn_geom<bf16_t>(C);
-    hipLaunchKernelGGL(gn_bwd_stats_kernel<bf16_t>, grid, dim3(g.nthreads), 0, st, (const bf16_t*)x, ldx,
-                       (const bf16_t*)dy, lddy, coef, mr, HW, C, g.VP, g.lanes, g.cpg, chunk, silu, sums, half_lgW);
+    hipLaunchKernelGGL((gn_bwd_stats_kernel<bf16_t, false>), grid, dim3(g.nthreads), 0, st, (const bf16_t*)x, ldx,
+                       (const bf16_t*)dy, lddy, coef, mr, HW, C, g.VP, g.lanes, g.cpg, chunk, silu, sums, half_lgW, nullptr, nullptr);
   } else {
     GnGeom g = gn_geom<float>(C);
-    hipLaunchKernelGGL(gn_bwd_stats_kernel<float>, grid, dim3(g.nthreads), 0, st, (const float*)x, ldx,
-                       (const float*)dy, lddy, coef, mr, HW, C, g.VP, g.lanes, g.cpg, chunk, silu, sums, half_lgW);
+    if (det)
+      hipLaunchKernelGGL((gn_bwd_stats_kernel<float, true>), grid, dim3(g.nthreads), (size_t)g.lanes * C * 2 * sizeof(float), st, (const float*)x, ldx,
+                         (const float*)dy, lddy, coef, mr, HW, C, g.VP, g.lanes, g.cpg, chunk, silu, sums, half_lgW, (double*)det->slab, det->cnt);
+    else
+      hipLaunchKernelGGL((gn_bwd_stats_kernel<float, false>), grid, dim3(g.nthreads), 0, st, (const float*)x, ldx,
+                         (const float*)dy, lddy, coef, mr, HW, C, g.VP, g.lanes, g.cpg, chunk, silu, sums, half_lgW, nullptr, nullptr);
   }
   prof_end(st);
   KDIP_LAUNCH_CHECK();

@@ -242,26 +242,28 @@ int resize_axis(hipStream_t st, const float* x, const float* w, const int* fov, 
                      n_out, other, axis, planes, out);
   KDIP_LAUNCH_CHECK(); return KDIP_OK;
 }
+// adjoint of resize_axis as a GATHER: input element `src` collects g[o] * w[o][t] over every (o, t) whose field of view hits it, in
+// (o, t) order -- no atomics, so the result does not depend on the order blocks arrive in (the scatter form added with fp32 atomics)
 __global__ void resize_axis_adj_kernel(const float* __restrict__ g, const float* __restrict__ w, const int* __restrict__ fov,
                                        int taps, int n_in, int n_out, int other, int axis, long planes, float* __restrict__ out) {
-  GRID_STRIDE(i, planes * (long)n_out * other) {
-    long p = i / ((long)n_out * other); int rc = (int)(i % ((long)n_out * other));
-    int o, q;
-    if (axis == 1) { q = rc / n_out; o = rc % n_out; } else { o = rc / other; q = rc % other; }
-    float* op = out + p * (long)n_in * other;
-    float gv = g[i];
-    for (int t = 0; t < taps; ++t) {
-      int src = fov[o * taps + t];
-      float* dst = (axis == 1) ? op + (long)q * n_in + src : op + (long)src * other + q;
-      atomicAdd(dst, gv * w[o * taps + t]);
+  GRID_STRIDE(i, planes * (long)n_in * other) {
+    long p = i / ((long)n_in * other); int rc = (int)(i % ((long)n_in * other));
+    int src, q;
+    if (axis == 1) { q = rc / n_in; src = rc % n_in; } else { src = rc / other; q = rc % other; }
+    const float* gp = g + p * (long)n_out * other;
+    float s = 0.f;
+    for (int o = 0; o < n_out; ++o) {
+      const float gv = (axis == 1) ? gp[(long)q * n_out + o] : gp[(long)o * other + q];
+      for (int t = 0; t < taps; ++t)
+        if (fov[o * taps + t] == src) s += gv * w[o * taps + t];
     }
+    out[i] = s;
   }
 }
 int resize_axis_adj(hipStream_t st, const float* g, const float* w, const int* fov, int taps, int n_in, int n_out, int other,
                     int axis, long planes, float* out) {
   ProfScope ps_(st, PC_OP_RESIZE, (double)planes * other * ((double)n_in + n_out) * sizeof(float), "resize_adj", planes, n_in, n_out, axis);
-  KDIP_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(float) * planes * n_in * other, st));
-  hipLaunchKernelGGL(resize_axis_adj_kernel, dim3(pw_grid(planes * (long)n_out * other)), dim3(256), 0, st, g, w, fov, taps,
+  hipLaunchKernelGGL(resize_axis_adj_kernel, dim3(pw_grid(planes * (long)n_in * other)), dim3(256), 0, st, g, w, fov, taps,
                      n_in, n_out, other, axis, planes, out);
   KDIP_LAUNCH_CHECK(); return KDIP_OK;
 }
@@ -487,25 +489,37 @@ int clamp_pm1(hipStream_t st, const float* x, long n, float* out) {
 }
 
 // --------------------------------------------------------------- per-sample reductions ----
-__global__ void dot_kernel(const float* __restrict__ a, const float* __restrict__ b, long per, double* __restrict__ out) {
-  // grid (chunks, B)
-  __shared__ double sh[4];
-  const int bidx = blockIdx.y;
+// One block per sample, fixed thread -> element assignment, xor-butterfly wave sums, wave partials added in wave order: the same
+// additions in the same order on every run (the CG trajectory and the DPS norm are reproducible bit for bit; a multi-block
+// reduction through fp64 atomics was not).  ~10 us for 196 608 elements: 2 dots per CG iteration, < 0.5 % of a guided call.
+__global__ __launch_bounds__(1024) void dot_kernel(const float* __restrict__ a, const float* __restrict__ b, long per, double* __restrict__ out) {
+  __shared__ double sh[16];
+  const int bidx = blockIdx.x;
   const float* ap = a + (long)bidx * per; const float* bp = b + (long)bidx * per;
-  float s = 0.f;
-  long chunk = (per + gridDim.x - 1) / gridDim.x;
-  long i0 = (long)blockIdx.x * chunk, i1 = i0 + chunk < per ? i0 + chunk : per;
-  for (long i = i0 + threadIdx.x; i < i1; i += blockDim.x) s += ap[i] * bp[i];
-  double d = wave_sum_d((double)s);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const bool vec = (per % 4 == 0) && (((uintptr_t)ap | (uintptr_t)bp) % 16 == 0);
+  if (vec) {
+    const float4* a4 = (const float4*)ap; const float4* b4 = (const float4*)bp;
+    for (long i = threadIdx.x; i < per / 4; i += 1024) {
+      const float4 u = a4[i], v = b4[i];
+      s0 += u.x * v.x; s1 += u.y * v.y; s2 += u.z * v.z; s3 += u.w * v.w;
+    }
+  } else {
+    for (long i = threadIdx.x; i < per; i += 1024) s0 += ap[i] * bp[i];
+  }
+  double d = wave_sum_d(((double)s0 + (double)s1) + ((double)s2 + (double)s3));
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = d;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(&out[bidx], sh[0] + sh[1] + sh[2] + sh[3]);
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += sh[w];
+    out[bidx] = t;
+  }
 }
 int cg_dot(hipStream_t st, const float* a, const float* b, int B, long per, double* out) {
   ProfScope ps_(st, PC_OP_POINTWISE, (double)B * per * sizeof(float) * 2, "cg_dot", B, per);
-  KDIP_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(double) * B, st));
-  int chunks = (int)((per + 4095) / 4096); if (chunks > 256) chunks = 256; if (chunks < 1) chunks = 1;
-  hipLaunchKernelGGL(dot_kernel, dim3(chunks, B), dim3(256), 0, st, a, b, per, out);
+  hipLaunchKernelGGL(dot_kernel, dim3(B), dim3(1024), 0, st, a, b, per, out);
   KDIP_LAUNCH_CHECK(); return KDIP_OK;
 }
 __global__ void sqrt_d2f_kernel(const double* in, int B, float* out) {

@@ -279,6 +279,23 @@ struct Ctx {
 
 double* new_sums(Ctx& c, int B) { return (double*)c.u->zeros.alloc(sizeof(double) * B * 64); }
 
+// deterministic modes: a slab for one launch's block partials (scratch arena: transient, planned by the dry run like every other
+// buffer) + the handle's counters; returns false (atomics path) for the bf16 mode
+bool det_ws(Ctx& c, size_t slab_bytes, DetWs& w) {
+  if (!c.u->det) return false;
+  w.slab = c.u->scratch.alloc(slab_bytes); w.slab_bytes = slab_bytes;
+  w.cnt = c.u->det_cnt; w.ncnt = c.u->det_ncnt;
+  return true;
+}
+size_t det_gn_bytes(int B, long HW) {      // gn_stats / gn_bwd_stats: [B][chunks][64] doubles, chunks <= max(1024 / B, HW / 256) + 1
+  long chunks = (1024 + B - 1) / B;
+  if (HW / 256 + 1 < chunks) chunks = HW / 256 + 1;
+  return (size_t)B * (chunks + 1) * 64 * sizeof(double);
+}
+size_t det_conv_bytes(int B, int H, int W, int Cout) {      // fused conv statistics: [tiles of 128 pixels][Cout / 4 vectors][2] floats
+  return (size_t)B * (((long)H * W + 127) / 128) * ((Cout + 127) / 128 * 128 / 4) * 2 * sizeof(float);
+}
+
 // pool_W > 0: y / pool_x receive the 2x2-average-pooled activated / raw tensors instead (downsampling ResBlock)
 // y == nullptr: statistics + coefficients only (the apply is fused into the consuming conv's input staging, conv3.hip)
 // fold: when given (and y == nullptr: the apply is fused into the consuming conv), NO coefficient kernel is launched either -- the
@@ -316,7 +333,9 @@ int gn_forward(Ctx& c, const void* x, long ldx, int B, long HW, const GnW& g, co
   }
   if (!stats) {
     stats = new_sums(c, B);
-    RUN(gn_stats(c.st, c.dt, x, ldx, B, HW, g.C, stats, 1));
+    DetWs dw;
+    const bool dd = det_ws(c, det_gn_bytes(B, HW), dw);
+    RUN(gn_stats(c.st, c.dt, x, ldx, B, HW, g.C, stats, 1, dd ? &dw : nullptr));
   }
   if (do_fold) {
     fold->fold_stats = stats; fold->fold_stats2 = stats2; fold->fold_C1 = mC1; fold->fold_gamma = g.gamma; fold->fold_beta = g.beta;
@@ -343,7 +362,9 @@ int gn_backward(Ctx& c, const void* x, long ldx, const void* dy, long lddy, cons
   double* sums = fused_sums;
   if (!sums) {
     sums = new_sums(c, B);
-    RUN(gn_bwd_stats(c.st, c.dt, x, ldx, dy, lddy, coef, mr, B, HW, C, silu, sums, 1, half_lgW));
+    DetWs dw;
+    const bool dd = det_ws(c, det_gn_bytes(B, HW), dw);
+    RUN(gn_bwd_stats(c.st, c.dt, x, ldx, dy, lddy, coef, mr, B, HW, C, silu, sums, 1, half_lgW, dd ? &dw : nullptr));
   }
   RUN(gn_bwd_apply(c.st, c.dt, x, ldx, dy, lddy, coef, mr, sums, B, HW, C, silu, addend, lda, dx, lddx, addend2, lda2, half_lgW));
   return KDIP_OK;
@@ -403,13 +424,16 @@ int conv_f(Ctx& c, const ConvW& w, const void* x, long ldx, int B, int H, int W,
   ConvStats stt;
   stt.in_ups = in_ups; stt.res_ups = res_ups;
   if (tf_coef) { stt.tf_coef = tf_coef; stt.tf_silu = 1; }
+  DetWs dw;
   if (stats_ok) {
     stt.mode = 1;
     stt.sums = new_sums(c, B);
     c.u->fused_stats[std::make_pair((const void*)y, w.cout)] = stt.sums;
+    if (det_ws(c, det_conv_bytes(B, H, W, w.cout), dw)) stt.det = &dw;
   }
+  stt.sk_det = c.u->det ? 1 : 0;
   RUN(conv_forward(c.st, c.cdt(), w.ntaps, x, ldx, B, H, W, w.cin_pad, w.wf, w.bias, w.cout, y, ldy, res, ldr, out_f32, 1.f, w.cin,
-                   (stt.mode || in_ups || res_ups || tf_coef) ? &stt : nullptr, c.u->sk_ws, c.u->sk_ws_floats));
+                   (stt.mode || in_ups || res_ups || tf_coef || stt.sk_det) ? &stt : nullptr, c.u->sk_ws, c.u->sk_ws_floats));
   return KDIP_OK;
 }
 // input-gradient: x here is dL/d(out) with >= cin_pad_b channels available (zero padded when cout % 32 != 0)
@@ -452,13 +476,16 @@ int conv_b(Ctx& c, const ConvW& w, const void* g, long ldg, int B, int H, int W,
     RUN(amax_bits_sampled(c.st, (const float*)g, ((long)B * H * W - 1) * ldg + w.cin_pad_b, aw));      // (the span of a channel-slice view)
     stt.x3_amax = aw;
   }
+  DetWs dw;
   if (stats_ok) {
     stt.mode = 2; stt.silu = gn_silu; stt.x = gn_x; stt.ldx = gn_ldx; stt.coef = gn_coef; stt.mr = gn_mr;
     stt.sums = new_sums(c, B);
     *sums_out = stt.sums;
+    if (det_ws(c, det_conv_bytes(B, H, W, w.cin), dw)) stt.det = &dw;
   }
+  stt.sk_det = c.u->det ? 1 : 0;
   RUN(conv_forward(c.st, c.cdt(), w.ntaps, g, ldg, B, H, W, w.cin_pad_b, w.wb, nullptr, w.cin, y, ldy, res, ldr, out_f32, 1.f, w.cout,
-                   (stt.mode || stt.x3_amax) ? &stt : nullptr, c.u->sk_ws, c.u->sk_ws_floats));
+                   (stt.mode || stt.x3_amax || stt.sk_det) ? &stt : nullptr, c.u->sk_ws, c.u->sk_ws_floats));
   return KDIP_OK;
 }
 }  // namespace
@@ -628,8 +655,17 @@ int UNet::forward_impl(hipStream_t st, const float* x_nchw, const float* t, int 
     for (auto& b : inp) upd(b);
     upd(mid);
     for (auto& b : out) upd(b);
-    sk_ws_floats = (long)B * 256 * maxc;
-    sk_ws = (float*)zeros.alloc(sizeof(float) * sk_ws_floats);
+    if (det) {
+      // deterministic modes: one slab per K split, plain stores, nothing to keep zeroed (persist arena: lives through the VJP too);
+      // the arrival counters of the ordered reductions sit in the zeros arena (cleared here, kept zero by each launch's last block)
+      sk_ws_floats = (long)B * 256 * maxc * 16;      // 16 = KDIP_SPLITK_MAX (conv.hip)
+      sk_ws = (float*)persist.alloc(sizeof(float) * sk_ws_floats);
+      det_ncnt = B;
+      det_cnt = (unsigned*)zeros.alloc(sizeof(unsigned) * B);
+    } else {
+      sk_ws_floats = (long)B * 256 * maxc;
+      sk_ws = (float*)zeros.alloc(sizeof(float) * sk_ws_floats);
+    }
   }
   int H = cfg.image_size, W = cfg.image_size;
   const int mc = cfg.model_channels, ted = mc * 4;

@@ -132,6 +132,14 @@ class UNetModel:
             raise ValueError("mode must be 'vjp' or 'launch'")
         L.check(self.lib.kdip_unet_x3_window(self._h, 1 if mode == "launch" else 0))
 
+    def set_deterministic(self, on=True):
+        """dtype "f32" / "bf16x3" only (default on): fixed-order cross-block reductions, two runs of one call are bitwise equal
+        (csrc/det.h).  Off = the floating-point atomics of the bf16 mode (A/B timing).  Returns the previous setting."""
+        rc = self.lib.kdip_unet_deterministic(self._h, 1 if on else 0)
+        if rc < 0:
+            L.check(rc)
+        return bool(rc)
+
     def vjp(self, cot):
         """(d out / d x_in)^T cot for the last forward; cot [B,6,S,S] -> [B,3,S,S]."""
         if not (cot.is_cuda and cot.dtype == torch.float32 and cot.device == self.device):

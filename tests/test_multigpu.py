@@ -55,11 +55,21 @@ def test_compute_features_rccl_world2(tmp_path):
     assert r.stdout.count("ok") == 2
 
 
+def test_bench_gpus_flag_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the driver's command line) starts its two ranks itself; `--topology-only`
+    stops after the rendezvous, so this runs on the CPU container too (gloo)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--topology-only"], capture_output=True, text=True, timeout=600,
+                       cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks"] == 2 and line["backend"] in ("gloo", "nccl"), line
+
+
 @pytest.mark.gpu2
 def test_bench_two_gpus_reports_topology():
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29543", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-           "--no-roofline"]
+    # no torchrun in front: bench.py launches its ranks itself (rank 0 prints the one JSON line)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1800, cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
