@@ -81,6 +81,11 @@ long kdip_unet_workspace_generation(kdip_unet* u);
  * back towards bf16's, never to inf).  per_launch = 1: every dgrad launch derives its scale from a sampled max of its own input (one
  * extra ~4 us launch each, +2 % per guided call): f32-grade whatever the network's backward gains. */
 int kdip_unet_x3_window(kdip_unet* u, int per_launch);
+/* (no reference counterpart) KDIP_BF16X3 handles: *flags_host = bit 0: since the last reset some conv launch staged an activation /
+ * gradient operand outside the fp16 window of its tail planes (|a * 2^sa| > 65504: that product fell back towards bf16 accuracy);
+ * bit 1: a weight of this handle was outside the window when it was packed (|w| > 255.9).  0 = every product of every conv carried its
+ * full split precision.  Synchronises `stream`. */
+int kdip_unet_x3_saturated(kdip_unet* u, void* stream, int reset, int* flags_host);
 /* (no reference counterpart) A/B switch of the fixed-order reductions of a KDIP_F32 / KDIP_BF16X3 handle (default on; off = the
  * floating-point atomics of the KDIP_BF16 mode: measures what reproducibility costs).  Returns the previous setting (0 | 1) or < 0. */
 int kdip_unet_deterministic(kdip_unet* u, int on);

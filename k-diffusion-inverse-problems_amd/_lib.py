@@ -26,6 +26,7 @@ SIGNATURES = {
     "kdip_unet_workspace_generation": (C.c_long, [VP]),
     "kdip_unet_x3_window": (C.c_int, [VP, C.c_int]),
     "kdip_unet_deterministic": (C.c_int, [VP, C.c_int]),
+    "kdip_unet_x3_saturated": (C.c_int, [VP, VP, C.c_int, C.POINTER(C.c_int)]),
     "kdip_op_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(VP)]),
     "kdip_op_destroy": (None, [VP]),
     "kdip_op_set_psf": (C.c_int, [VP, VP, C.c_int, C.c_int]),

@@ -1,4 +1,5 @@
 // C ABI of libkdip_hip (see include/kdip.h for the contract and reference citations).
+#include <stdlib.h>
 #include <vector>
 #include <mutex>
 #include "../../include/kdip.h"
@@ -48,6 +49,7 @@ int kdip_unet_create(int device, int dtype, int image_size, int in_channels, int
   h->u.dt = dtype == KDIP_BF16 ? DT_BF16 : DT_F32;
   h->u.cdt = dtype == KDIP_BF16X3 ? DT_F32X3 : h->u.dt;
   h->u.det = dtype != KDIP_BF16;        // fp32-storage modes: fixed-order reductions (det.h)
+  if (const char* e = getenv("KDIP_DET")) { if (atoi(e) == 0) h->u.det = false; }      // A/B timing aid (same as kdip_unet_deterministic(u, 0))
   h->u.cfg.image_size = image_size; h->u.cfg.in_channels = in_channels; h->u.cfg.model_channels = model_channels;
   h->u.cfg.out_channels = out_channels; h->u.cfg.num_res_blocks = num_res_blocks;
   h->u.cfg.attention_ds.assign(attention_ds, attention_ds + n_attention_ds);
@@ -113,6 +115,17 @@ int kdip_unet_x3_window(kdip_unet* u, int per_launch) {
     u->u.have_stash = false;           // ... and a VJP needs a forward made under the new plan
     ++u->u.ws_generation;              // graphs captured under the other window mode replay its kernels / arena offsets: invalidate them (graphs.py keys on this)
   }
+  return KDIP_OK;
+}
+int kdip_unet_x3_saturated(kdip_unet* u, void* stream, int reset, int* flags_host) {
+  KDIP_REQUIRE(u && flags_host, "null argument");
+  KDIP_REQUIRE(u->u.cdt == DT_F32X3 && u->u.x3_sat, "x3_saturated: the handle was not created with KDIP_BF16X3 (or is not finalized)");
+  KDIP_HIP_CHECK(hipSetDevice(u->u.device));
+  unsigned w = 0;
+  KDIP_HIP_CHECK(hipMemcpyAsync(&w, u->u.x3_sat, sizeof(w), hipMemcpyDeviceToHost, ST(stream)));
+  if (reset) KDIP_HIP_CHECK(hipMemsetAsync(u->u.x3_sat, 0, sizeof(unsigned), ST(stream)));
+  KDIP_HIP_CHECK(hipStreamSynchronize(ST(stream)));
+  *flags_host = (int)(w & 1u) | (u->u.x3_weight_sat > 0 ? 2 : 0);
   return KDIP_OK;
 }
 int kdip_unet_deterministic(kdip_unet* u, int on) {

@@ -125,6 +125,7 @@ struct ConvParams {
   int TH, TW, TB;                 // patch geometry (powers of two), TH*TW*TB == BM
   int lgTW, lgTHW;
   int magicRow, magicPatch;       // ceil(2^20 / (TW+2*halo)), ceil(2^20 / ((TH+2*halo)*(TW+2*halo)))
+  int rowpad;                     // bytes appended to every LDS patch row so that the row pitch is a multiple of 256 B (see launch_cfg2)
   int tilesX, tilesY, mtiles;     // per-image tiles, total M tiles
   int out_f32;                    // store fp32 regardless of T
   float alpha;                    // output scale (applied before bias)
@@ -148,9 +149,11 @@ struct ConvParams {
   const float* st_mr;             // mode 2: [B][32][2] (mean, rstd)
   const float* tf_coef; int tf_silu;   // split precision, 3x3: the input is a GroupNorm INPUT; silu?(a*x + b) with (a, b) = tf_coef[B][Cin][2] is applied while
                                   // the patch is staged (conv zero padding applies to the transformed tensor); one image per tile only
-  float* det_slab; unsigned* det_cnt; size_t det_slab_bytes; int det_ncnt;   // deterministic modes (det.h): fused statistics go block by block into det_slab [B][tiles per image][n-blocks][BN/4][2] and are
-                                  // added in slot order by the last block of each image (counter det_cnt[image]); split-K partials go to per-split slabs of sk_ws (sk_det)
+  float* det_slab; size_t det_slab_bytes;   // deterministic modes (det.h): fused statistics go block by block into det_slab [B][tiles per image][n-blocks][BN/4][2] and are
+                                  // added in slot order by conv_stats_finish_kernel; split-K partials go to per-split slabs of sk_ws (sk_det)
   int sk_det;
+  unsigned* x3_sat;               // split precision: optional device word, bit 0 is set when an A operand (after its power-of-two scaling) leaves the fp16 window
+                                  // (|a| > 65504: its fp16 tail planes saturate and the product degrades towards the bf16 head's accuracy)
   const unsigned* x3_amax;        // split precision: optional device word = bits of max |x| of the input's tensor family (sets the fp16 window of the A operand)
   unsigned long long* dbg;        // KDIP_TIMING builds: [grid][8] s_memrealtime stamps (start, staged, k-loop done, end, store loop done, sync 1, sync 2)
 };
@@ -168,7 +171,12 @@ int conv_debug_timing(void* buf, int H, int cin, int cout, int st_mode) {
 #define KDIP_STAMP(i) do { } while (0)
 #endif
 
-constexpr int KC = 32;            // input channels per B-pipeline stage (one tap of one 32-channel sub-chunk)
+constexpr int KC = 32;            // input channels per B-pipeline stage (one tap of one 32-channel sub-chunk); padding granule of Cin
+#ifndef KDIP_X3_KC
+#define KDIP_X3_KC 32             // split-precision 3x3 instantiations: channels per LDS stage.  16 = one k-step per stage: the operand queues (3 A planes + 2 B planes
+#endif                            // per fragment) of a 32-channel stage do not fit the register file next to the accumulators (hipcc then re-reads fragments right before use)
+// channels per sub-chunk of an instantiation
+template <typename T, int NTAPS> constexpr int kc_of() { return (std::is_same<T, f32x3_t>::value && NTAPS == 9) ? KDIP_X3_KC : KC; }
 #ifndef KDIP_CONV1_NT_LOAD
 #define KDIP_CONV1_NT_LOAD 0     // non-temporal input staging loads of the 1x1 convs: big-map class -3 %, small-map classes +2-4 %, step unchanged
 #endif
@@ -240,6 +248,9 @@ constexpr int KC = 32;            // input channels per B-pipeline stage (one ta
 #ifndef KDIP_X3_OCC
 #define KDIP_X3_OCC 2        // split-precision 128x128 tiles: resident blocks per CU the register budget is set for
 #endif
+#ifndef KDIP_ROWPAD
+#define KDIP_ROWPAD 1        // 256-byte-multiple LDS row pitch of the 16-pixel-wide 3x3 patches (conflict-free fragment reads; 0: natural pitch, A/B builds)
+#endif
 #ifndef KDIP_X3_TF_APF
 #define KDIP_X3_TF_APF 1     // GroupNorm-staging instantiation: 1 = A-fragment prefetch + one weight stage in flight; 0 = no prefetch + two stages
 #endif
@@ -260,7 +271,7 @@ constexpr int KC = 32;            // input channels per B-pipeline stage (one ta
 // Every wave holds (s1, s2) of its 4-channel vectors (lanes < LPR after the row reduction).  Waves sharing a channel range (same wn)
 // park their pairs in their own LDS rows and thread v adds the WAVES_M rows in order (no LDS atomics: with four row waves their
 // arrival order would change the rounding).  Then either one fp64 atomic pair per vector (bf16 throughput mode), or -- deterministic
-// modes -- the pair goes to this block's slot of the slab and the last block of the image adds all slots in order (det.h).
+// modes -- the pair goes to this block's slot of the slab; a finish kernel adds all slots in a fixed order (det.h).
 template <int WAVES_M, int BN, int LPR>
 __device__ __forceinline__ void conv_stats_handover(const ConvParams& p, float s1, float s2, float* sred, int tid, int lane, int wm, int wn, int ntb,
                                                     int nblkN, int img0, int trem, int tpi) {
@@ -290,39 +301,54 @@ __device__ __forceinline__ void conv_stats_handover(const ConvParams& p, float s
     }
     return;
   }
-  // slot of (image, tile, n-block, vector): [img][trem][ntb][BN/4][2]
-  float* slab = p.det_slab + ((long)img0 * tpi) * nblkN * (BN / 4) * 2;
+  // slot of (image, tile, n-block, vector): [img][trem][ntb][BN/4][2]; conv_stats_finish_kernel adds the slots
   if (tid < BN / 4) {
-    float* slot = slab + (((long)trem * nblkN + ntb) * (BN / 4) + tid) * 2;
-    det_store(slot, live ? a : 0.f);
-    det_store(slot + 1, live ? q : 0.f);
+    float2* slot = (float2*)p.det_slab + (((long)img0 * tpi + trem) * nblkN + ntb) * (BN / 4) + tid;
+    *slot = live ? make_float2(a, q) : make_float2(0.f, 0.f);
   }
-  if (!det_last_block(p.det_cnt + img0, (unsigned)(tpi * nblkN))) return;
-  // last block of image img0: thread (group g = tid >> 3, segment sg = tid & 7) adds the group's vectors over its range of tiles in
-  // order (fp64); the 8 segments of a group are then added in order.  256 threads (every tile configuration has 4 waves).
-  double* dsh = (double*)sred;                      // [32][8][2] doubles = 4 KiB (the transpose regions in front are dead)
-  {
-    const int g = tid >> 3, sg = tid & 7;
-    const int t0 = (int)((long)tpi * sg / 8), t1 = (int)((long)tpi * (sg + 1) / 8);
-    const int v0 = g * cpg / 4, v1 = (g + 1) * cpg / 4;        // cpg % 4 == 0 (launch precondition of the fused statistics)
+}
+
+// Deterministic modes, second stage (one block of 256 threads per image): the image's slots form tpi rows of NV = Cout_pad / 4 float2
+// (one row per tile); thread (sub = tid / NVB, v = tid % NVB) adds, for each of its vectors, tiles sub, sub + S, sub + 2 S, ... in that
+// order (fp64; coalesced rows, 8 loads in flight), the S partial sums of a vector are then added in order and the vectors of a group
+// in order: one fixed summation tree.  WRITES sums[b][32][2].
+__global__ __launch_bounds__(256) void conv_stats_finish_kernel(const float2* __restrict__ slab, int tpi, int NV, int cpg, double* __restrict__ sums) {
+  __shared__ double dsh[512];
+  extern __shared__ __attribute__((aligned(16))) double gsh[];      // [NV][2]
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const float2* rows = slab + (long)b * tpi * NV;
+  const int NVB = NV < 256 ? NV : 256;              // vectors handled per pass
+  const int S = 256 / NVB;                          // tile sub-sequences
+  for (int vb = 0; vb < NV; vb += NVB) {
+    const int sub = tid / NVB, v = vb + tid % NVB;
     double da = 0.0, dq = 0.0;
-    for (int t = t0; t < t1; ++t)
-      for (int v = v0; v < v1; ++v) {
-        const float* slot = slab + (((long)t * nblkN + v / (BN / 4)) * (BN / 4) + v % (BN / 4)) * 2;
-        da += (double)det_load(slot);
-        dq += (double)det_load(slot + 1);
+    if (sub < S && v < NV) {
+      int t = sub;
+      for (; t + 7 * S < tpi; t += 8 * S) {
+        float2 w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = rows[(long)(t + u * S) * NV + v];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { da += (double)w[u].x; dq += (double)w[u].y; }
       }
-    __syncthreads();                                // (sred reads above are done in every thread)
-    dsh[(g * 8 + sg) * 2] = da;
-    dsh[(g * 8 + sg) * 2 + 1] = dq;
+      for (; t < tpi; t += S) { const float2 w = rows[(long)t * NV + v]; da += (double)w.x; dq += (double)w.y; }
+    }
+    __syncthreads();
+    dsh[tid * 2] = da; dsh[tid * 2 + 1] = dq;
+    __syncthreads();
+    if (tid < NVB && vb + tid < NV) {
+      double ra = 0.0, rq = 0.0;
+      for (int s2 = 0; s2 < S; ++s2) { ra += dsh[(s2 * NVB + tid) * 2]; rq += dsh[(s2 * NVB + tid) * 2 + 1]; }
+      gsh[(vb + tid) * 2] = ra; gsh[(vb + tid) * 2 + 1] = rq;
+    }
   }
   __syncthreads();
   if (tid < 64) {
     const int g = tid >> 1, k = tid & 1;
+    const int v0 = g * cpg / 4, v1 = (g + 1) * cpg / 4;          // cpg % 4 == 0 (launch precondition of the fused statistics)
     double r = 0.0;
-#pragma unroll
-    for (int sg = 0; sg < 8; ++sg) r += dsh[(g * 8 + sg) * 2 + k];
-    p.st_sums[((long)img0 * 32 + g) * 2 + k] = r;
+    for (int v = v0; v < v1; ++v) r += gsh[v * 2 + k];
+    sums[((long)b * 32 + g) * 2 + k] = r;
   }
 }
 
@@ -605,7 +631,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
   constexpr int BM = WAVES_M * MT * 32;
   constexpr int BN = WAVES_N * NT * 32;
   constexpr int KSTEP = Mma<T>::KSTEP;
-  constexpr int KS = KC / KSTEP;                       // k-steps per 32-channel sub-chunk
+  constexpr int KC = kc_of<T, NTAPS>();                // (shadows the namespace constant: this instantiation's sub-chunk width)
+  constexpr int KS = KC / KSTEP;                       // k-steps per sub-chunk
   constexpr int KCH = KC * SUBS;                       // channels per LDS stage
   constexpr int PIXB = KCH * Mma<T>::LDS_BPC + 16;     // padded LDS pixel stride (bytes)
   constexpr int VPP = KCH * (int)sizeof(T) / 16;       // 16-byte vectors per staged pixel (global side)
@@ -621,7 +648,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
   constexpr int EROWS = PERSIST_K ? 16 : 32;           // height of the fast epilogue's per-wave transpose region
   const int HW_ = p.TW + 2 * HALO, HH_ = p.TH + 2 * HALO;
   const int npix = p.TB * HH_ * HW_;
-  const int abuf_bytes = npix * PIXB;
+  const int ROWB = HW_ * PIXB + p.rowpad;              // LDS pitch of one halo-patch row
+  const int abuf_bytes = p.TB * HH_ * ROWB;
   const int nblkN = (p.ntilesN * 32 + BN - 1) / BN;
   const int tpi = p.tilesX * p.tilesY;                 // tiles per image (1 when TB>1)
   const T* xin = (const T*)p.x;
@@ -714,7 +742,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
     int m = (wm * MT + mt) * 32 + (lane & 31);
     int tb = m >> p.lgTHW, rr = m & ((1 << p.lgTHW) - 1);
     int ty = rr >> p.lgTW, tx = rr & (p.TW - 1);
-    abase[mt] = ((tb * HH_ + ty) * HW_ + tx) * PIXB + (lane >> 5) * 16;
+    abase[mt] = (tb * HH_ + ty) * ROWB + tx * PIXB + (lane >> 5) * 16;
   }
   // ---- B fragment pointers (uniform base per n-tile + lane)
   const int nt0 = ntb * (BN / 32) + wn * NT;           // first n-tile of this wave
@@ -783,6 +811,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
     // vectors: NTHREADS % VPP == 0); fetched here (L2-hot, 32 bytes) rather than with the patch loads: 8 fewer registers live
     // across the MFMA stages
     float4 tfk[2] = {make_float4(1.f, 0.f, 1.f, 0.f), make_float4(1.f, 0.f, 1.f, 0.f)};
+    float x3_peak = 0.f;                                 // largest |scaled operand| this thread staged in this chunk
     if (x3_tf) {
       const float4* cf = (const float4*)(p.tf_coef + ((long)img0 * p.Cin + (long)tf_chunk * KCH + (tid % VPP) * 4) * 2);
       tfk[0] = cf[0]; tfk[1] = cf[1];
@@ -809,10 +838,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
 #pragma unroll
             for (int e = 0; e < 4; ++e) f[e] *= x3_sa;
           }
+          if constexpr (X3M) x3_peak = fmaxf(x3_peak, fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3]))));
           const uint32_t h0 = pack_bf16x2(f[0], f[1]), h1 = pack_bf16x2(f[2], f[3]);
           const float r0 = f[0] - __uint_as_float(h0 << 16), r1 = f[1] - __uint_as_float(h0 & 0xffff0000u);
           const float r2 = f[2] - __uint_as_float(h1 << 16), r3 = f[3] - __uint_as_float(h1 & 0xffff0000u);
-          unsigned char* d = smem + buf * abuf_bytes + pix * PIXB + (v % VPP) * 8;
+          unsigned char* d = smem + buf * abuf_bytes + pix * PIXB + ((pix * p.magicRow) >> 20) * p.rowpad + (v % VPP) * 8;
           *(uint2*)d = make_uint2(h0, h1);
           if constexpr (X3M) {
             *(uint2*)(d + KCH * 2) = make_uint2(pack_f16x2_sat(f[0], f[1]), pack_f16x2_sat(f[2], f[3]));
@@ -822,8 +852,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
           }
         }
       } else {
-        if (pix < npix) *(uint4*)(smem + buf * abuf_bytes + pix * PIXB + (v % VPP) * 16) = areg[i];
+        if (pix < npix) *(uint4*)(smem + buf * abuf_bytes + pix * PIXB + ((pix * p.magicRow) >> 20) * p.rowpad + (v % VPP) * 16) = areg[i];
       }
+    }
+    if constexpr (X3M) {
+      if (x3_peak > 65504.f && p.x3_sat) atomicOr(p.x3_sat, 1u);      // (rare branch: nothing is issued while every operand is inside the window)
     }
   };
 
@@ -860,7 +893,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
   // A fragments of the next (sub, tap) stage are read from LDS one stage ahead, so the ds_reads
   // of stage s+1 are in flight under the MFMAs of stage s.
   auto load_a = [&](uint4 (&dst)[KS][MT][NPA], const unsigned char* abuf, int sub, int tap) {
-    const int toff = ((NTAPS == 9) ? ((tap / 3) * HW_ + (tap % 3)) * PIXB : 0) + sub * KC * (X3 ? 2 : (int)sizeof(T));
+    const int toff = ((NTAPS == 9) ? (tap / 3) * ROWB + (tap % 3) * PIXB : 0) + sub * KC * (X3 ? 2 : (int)sizeof(T));
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -1185,6 +1218,7 @@ __global__ void conv_splitk_finalize_kernel(float* __restrict__ ws, const float*
 template <typename T, int NTAPS, int WAVES_M, int WAVES_N, int MT, int NT, int SUBS>
 static int launch_cfg2(ConvParams& p, hipStream_t st) {
   constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32;
+  constexpr int KC = kc_of<T, NTAPS>();
   constexpr int PIXB = KC * SUBS * Mma<T>::LDS_BPC + 16;
   constexpr int HALO = (NTAPS == 9) ? 1 : 0;
   // 32-pixel-wide patches: an MFMA m-tile (32 rows) is one patch row, so the 16-lane groups of
@@ -1211,14 +1245,22 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
   int npix = TB * (TH + 2 * HALO) * (TW + 2 * HALO);
   if (npix > ((NTAPS == 1) ? BM : (BM == 256 ? 400 : 256)))
     return set_error(KDIP_ERR_UNSUPPORTED, "conv: halo patch too large (%d px)", npix);
-  size_t lds = (size_t)2 * npix * PIXB;
+  // LDS row pitch.  ds_read_b128 is served in four NON-contiguous 16-lane groups ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...;
+  // MI355X_MICROARCH.md, LDS): with 16-pixel patch rows a group takes pixels 0-3, 12-15 of one patch row and 4-11 of the next, and the
+  // 16-byte slot of pixel q of a row is (q * PIXB / 16) mod 16 with PIXB / 16 odd -- the sixteen pixels are on sixteen different slots
+  // exactly when consecutive rows start on the same slot, i.e. the row pitch is a multiple of 256 B.  The natural pitch (18 pixels x 80 /
+  // 144 / 208 B) is not: two of the sixteen slots were hit twice and every fragment read took two LDS cycles per group instead of one
+  // (SQ_LDS_BANK_CONFLICT = 48 % of SQ_LDS_IDX_ACTIVE, profiles/r04/pmc_x3_conv_micro.json).  Pad the rows (<= 240 B each).
+  p.rowpad = 0;
+  if (NTAPS == 9 && TW == 16 && KDIP_ROWPAD) p.rowpad = (int)((256 - ((TW + 2 * HALO) * PIXB) % 256) % 256);
+  const int rowb = (TW + 2 * HALO) * PIXB + p.rowpad;
+  size_t lds = (size_t)2 * TB * (TH + 2 * HALO) * rowb;
   const bool osz4 = p.out_f32 || sizeof(T) == 4;
   p.vec_epilogue = (p.Cout % 4 == 0) && (p.ldy % 4 == 0) && (!p.res || p.ldr % 4 == 0) &&
                    ((uintptr_t)p.y % (osz4 ? 16 : 8) == 0) && (!p.res || (uintptr_t)p.res % (sizeof(T) == 2 ? 8 : 16) == 0);
   if (p.vec_epilogue) {
-    // transpose regions + the statistics exchange: [WAVES_M][BN/4][2] floats, re-used as [32][8][2] doubles by the deterministic final sum
+    // transpose regions + the statistics exchange: [WAVES_M][BN/4][2] floats
     size_t xs = (size_t)WAVES_M * (BN / 4) * 2 * sizeof(float);
-    if (xs < 32 * 8 * 2 * sizeof(double)) xs = 32 * 8 * 2 * sizeof(double);
     size_t cl = (size_t)WAVES_M * WAVES_N * 32 * (NT * 32 * 4 + 16) + xs;
     if (cl > lds) lds = cl;
   }
@@ -1260,7 +1302,7 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
   // of 8 (one share per XCD); LDS = two A buffers + the half-height epilogue regions behind them
   p.persist = 0;
   if (KDIP_PERSIST && sizeof(T) == 2 && NTAPS == 9 && SUBS == 1 && p.fast_epilogue && p.Cout % BN == 0) {
-    const size_t plds = (size_t)2 * npix * PIXB + (size_t)WAVES_M * WAVES_N * 16 * (NT * 32 * 4 + 16) + (size_t)BN / 4 * 2 * sizeof(float) +
+    const size_t plds = (size_t)2 * TB * (TH + 2 * HALO) * rowb + (size_t)WAVES_M * WAVES_N * 16 * (NT * 32 * 4 + 16) + (size_t)BN / 4 * 2 * sizeof(float) +
                         (size_t)((NTAPS == 1 ? BM : 256) * (KC * SUBS * (int)sizeof(T) / 16) + WAVES_M * WAVES_N * 64 - 1) / (WAVES_M * WAVES_N * 64) *
                             (WAVES_M * WAVES_N * 64) * sizeof(int);                                   // + MAXV x NTHREADS parked offsets
     static std::mutex pmu;              // (experimental -DKDIP_PERSIST=1 builds only) occupancy cache shared by host threads
@@ -1296,7 +1338,7 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
   }
   p.sk_splits = splits;
   if (p.st_mode && p.det_slab) {
-    KDIP_REQUIRE(p.det_cnt && (size_t)p.mtiles * nblkN * (BN / 4) * 2 * sizeof(float) <= p.det_slab_bytes && p.B <= p.det_ncnt,
+    KDIP_REQUIRE((size_t)p.mtiles * nblkN * (BN / 4) * 2 * sizeof(float) <= p.det_slab_bytes,
                  "conv: deterministic-statistics workspace too small (%d tiles x %d n-blocks)", p.mtiles, nblkN);
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)splits), dim3(WAVES_M * WAVES_N * 64), lds, st, p);
@@ -1306,6 +1348,11 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
     using ST = std::conditional_t<std::is_same<T, f32x3_t>::value, float, T>;      // storage type
     hipLaunchKernelGGL(conv_splitk_finalize_kernel<ST>, dim3((unsigned)g), dim3(256), 0, st, p.sk_ws, p.bias, (const ST*)p.res, p.ldr, npix, p.Cout,
                        (ST*)p.y, p.ldy, p.sk_det ? splits : 0);
+  }
+  if (p.st_mode && p.det_slab) {
+    const int NV = nblkN * (BN / 4);
+    hipLaunchKernelGGL(conv_stats_finish_kernel, dim3(p.B), dim3(256), (size_t)NV * 2 * sizeof(double), st, (const float2*)p.det_slab, p.tilesX * p.tilesY, NV,
+                       p.Cout >> 5, p.st_sums);
   }
   prof_end(st);
   KDIP_LAUNCH_CHECK();
@@ -1374,8 +1421,9 @@ int conv_forward(hipStream_t st, DType dt, int ntaps, const void* x, long ldx, i
   p.st_mode = 0; p.st_silu = 0; p.st_sums = nullptr; p.st_x = nullptr; p.st_ldx = 0; p.st_coef = nullptr; p.st_mr = nullptr;
   p.in_ups = stt ? stt->in_ups : 0; p.res_ups = stt ? stt->res_ups : 0;
   p.x3_amax = stt ? stt->x3_amax : nullptr;
+  p.x3_sat = stt ? stt->x3_sat : nullptr;
   const DetWs* det = stt ? stt->det : nullptr;
-  p.det_slab = det ? (float*)det->slab : nullptr; p.det_cnt = det ? det->cnt : nullptr; p.det_slab_bytes = det ? det->slab_bytes : 0; p.det_ncnt = det ? det->ncnt : 0;
+  p.det_slab = det ? (float*)det->slab : nullptr; p.det_slab_bytes = det ? det->slab_bytes : 0;
   p.sk_det = stt ? stt->sk_det : 0;
   p.tf_coef = stt ? stt->tf_coef : nullptr; p.tf_silu = stt ? stt->tf_silu : 0;
   KDIP_REQUIRE(!p.tf_coef || (dt == DT_F32X3 && ntaps == 9 && (long)H * W >= 128 && ((uintptr_t)p.tf_coef % 16) == 0),
@@ -1423,6 +1471,9 @@ static uint16_t f32_to_f16_bits(float f) {
   return (uint16_t)(sign | (e << 10) | m);
 }
 
+std::atomic<long> g_x3_weight_sat{0};      // split-precision weights outside the fp16 window, counted by pack_conv_weight (read by UNet::finalize)
+long x3_weight_saturations() { return g_x3_weight_sat.load(); }
+
 void pack_conv_weight(DType dt, const float* w, int Cout, int Cin, int ntaps, int transpose_flip, int Cin_pad_out,
                       void* out) {
   // logical conv after optional transpose: Co x Ci
@@ -1443,6 +1494,7 @@ void pack_conv_weight(DType dt, const float* w, int Cout, int Cin, int ntaps, in
           for (int lane = 0; lane < 64; ++lane)
             for (int e = 0; e < 8; ++e) {
               const float v = W(nt * 32 + (lane & 31), ks * 16 + (lane >> 5) * 8 + e, tap) * X3_S;     // exact power-of-two scaling
+              if (KDIP_X3_MIXED && fabsf(v) > 65504.f) g_x3_weight_sat.fetch_add(1);                        // the f16 re-encoded head saturates (|w| > 255.9)
               const bf16_t hi = f32_to_bf16(v);
               o[idx + lane * 8 + e] = hi;
               const float lo = v - bf16_to_f32(hi);

@@ -144,6 +144,10 @@ int amax_bits_sampled(hipStream_t st, const float* x, long n, unsigned* out_zero
   const long nvec = n / 4;
   int stride = (int)(nvec / (64L * 1024));              // ~64 K sampled vectors at most
   if (stride < 1) stride = 1;
+  // an ODD stride: the NHWC pixel pitches here are powers of two (x 3 at most) vectors, and an even stride that divides the pitch would
+  // sample the same few channels of every k-th pixel (stride 512 at ld 256: channels 0..3 only); an odd one walks through all channel vectors
+  if (stride > 1) stride |= 1;
+  if (stride > 1 && stride % 3 == 0) stride += 2;
   long g = (nvec / stride + 255) / 256; if (g > 256) g = 256; if (g < 1) g = 1;
   hipLaunchKernelGGL(amax_bits_sampled_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float4*)x, nvec, stride, out_zeroed);
   KDIP_LAUNCH_CHECK();

@@ -18,10 +18,11 @@ struct ConvStats {
   // split-precision mode (DT_F32X3): device word holding the bits of max |x| of the tensor family the INPUT belongs to (the VJP's
   // cotangent), or null for inputs of O(1) scale (forward activations): sets the fp16 window of the A operand (conv.hip, Mma<f32x3_t>)
   const unsigned* x3_amax = nullptr;
+  unsigned* x3_sat = nullptr;      // ... and a device word whose bit 0 the kernel sets when a scaled operand leaves that window (|a| > 65504)
   // split-precision 3x3 convs on maps with >= 128 pixels: the input is a GroupNorm INPUT and silu?(a*x + b), (a, b) = tf_coef [B][Cin][2]
   // (gn_coef), is applied while the patch is staged -- the activated tensor never exists in HBM (as Conv3Fuse::tf 1 does for bf16)
   const float* tf_coef = nullptr; int tf_silu = 0;
-  // deterministic modes (det.h): fused statistics reduced in a fixed order through det->slab (counters det->cnt[image]); sk_det:
+  // deterministic modes (det.h): fused statistics reduced in a fixed order through det->slab (+ a finish kernel); sk_det:
   // sk_ws is NOT pre-zeroed and holds one slab [B*H*W][Cout] per K split (sk_ws_floats bounds the number of splits), summed in
   // split order by the finalize pass
   const DetWs* det = nullptr; int sk_det = 0;
@@ -35,6 +36,7 @@ int conv_forward(hipStream_t st, DType dt, int ntaps, const void* x, long ldx, i
 // sk_ws: optional fp32 split-K workspace of sk_ws_floats floats, all zero on entry and on return; when given, under-filled
 // launches (small-spatial layers) split their K range over blockIdx.y and reduce through it
 size_t packed_weight_bytes(DType dt, int ntaps, int Cin_pad, int Cout);
+long x3_weight_saturations();       // running count of DT_F32X3 weights packed so far whose scaled value left the fp16 window (|w| > 255.9)
 int conv_debug_timing(void* buf, int H, int cin, int cout, int st_mode);   // -DKDIP_TIMING=1 diagnostic builds only
 void pack_conv_weight(DType dt, const float* w, int Cout, int Cin, int ntaps, int transpose_flip, int Cin_pad_out,
                       void* out);

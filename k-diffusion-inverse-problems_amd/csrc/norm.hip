@@ -31,11 +31,11 @@ template <typename T> static GnGeom gn_geom(int C) {
 // ---------------------------------------------------------------- forward statistics ----
 // Fixed-order combine of per-thread partial sums (deterministic modes): every thread parks its EPV (sum 1, sum 2) pairs in LDS as
 // [pixel lane][channel][2]; thread (group g, k) then adds group g's lanes x cpg values in index order (fp64) -- block-size and
-// arrival-order independent.  The block's 64 results go to slot blockIdx.x of image b's slab row; the last block of the image adds
-// the slots in order and WRITES the image's statistics (det.h).
+// arrival-order independent.  The block's 64 results go to slot blockIdx.x of image b's slab row; gn_det_finish_kernel adds the
+// slots in a fixed tree and WRITES the image's statistics (det.h).
 template <int EPV>
 __device__ __forceinline__ void gn_det_combine(const float (&v1)[EPV], const float (&v2)[EPV], bool active, int vi, int pl, int lanes, int C,
-                                               int cpg, float* lsh, double* slab, unsigned* cnt, double* __restrict__ out) {
+                                               int cpg, float* lsh, double* slab) {
   const int tid = threadIdx.x, b = blockIdx.y;
   if (active) {
 #pragma unroll
@@ -51,21 +51,33 @@ __device__ __forceinline__ void gn_det_combine(const float (&v1)[EPV], const flo
     double a = 0.0;
     for (int l = 0; l < lanes; ++l)
       for (int c = g * cpg; c < (g + 1) * cpg; ++c) a += (double)lsh[((long)l * C + c) * 2 + k];
-    det_store(row + tid, a);
+    row[tid] = a;
   }
-  if (det_last_block(cnt + b, gridDim.x)) {
-    if (tid < 64) {
-      double a = 0.0;
-      const double* r0 = slab + (long)b * gridDim.x * 64 + tid;
-      for (unsigned j = 0; j < gridDim.x; ++j) a += det_load(r0 + (long)j * 64);
-      out[(long)b * 64 + tid] = a;
-    }
+}
+// out[b][64] = sum over the n chunk slots of image b (grid = B blocks of 256 threads): thread (part = tid >> 6, k = tid & 63) adds slots
+// part, part + 4, ... (coalesced 512-byte rows, 8 loads in flight), the four parts are then added in order
+__global__ __launch_bounds__(256) void gn_det_finish_kernel(const double* __restrict__ slab, int n, double* __restrict__ out) {
+  __shared__ double dsh[256];
+  const int tid = threadIdx.x, b = blockIdx.x, part = tid >> 6, k = tid & 63;
+  const double* r0 = slab + (long)b * n * 64;
+  double a = 0.0;
+  int j = part;
+  for (; j + 28 < n; j += 32) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = r0[(long)(j + 4 * u) * 64 + k];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a += v[u];
   }
+  for (; j < n; j += 4) a += r0[(long)j * 64 + k];
+  dsh[part * 64 + k] = a;
+  __syncthreads();
+  if (tid < 64) out[(long)b * 64 + tid] = ((dsh[tid] + dsh[64 + tid]) + dsh[128 + tid]) + dsh[192 + tid];
 }
 
 template <typename T, bool DET>
 __global__ void gn_stats_kernel(const T* __restrict__ x, long ldx, long HW, int C, int VP, int lanes, int cpg,
-                                long chunk, double* __restrict__ stats, double* det_slab, unsigned* det_cnt) {
+                                long chunk, double* __restrict__ stats, double* det_slab) {
   constexpr int EPV = TypeInfo<T>::EPV;
   __shared__ double sh[32][2];
   extern __shared__ __attribute__((aligned(16))) float gn_lsh[];      // DET: [lanes][C][2]
@@ -104,7 +116,7 @@ __global__ void gn_stats_kernel(const T* __restrict__ x, long ldx, long HW, int 
     }
   }
   if (DET) {       // (block-uniform)
-    gn_det_combine<EPV>(s, ss, pl < lanes, vi, pl, lanes, C, cpg, gn_lsh, det_slab, det_cnt, stats);
+    gn_det_combine<EPV>(s, ss, pl < lanes, vi, pl, lanes, C, cpg, gn_lsh, det_slab);
     return;
   }
   __syncthreads();
@@ -121,9 +133,10 @@ static long pick_chunk(long HW, int B) {
 
 // DetWs given (deterministic modes): fixed-order reduction through det->slab ([B][chunks][64] doubles), statistics WRITTEN by the
 // last block of each image (no pre-zeroing needed)
+static size_t gn_det_lds(int lanes, int C) { return (size_t)lanes * C * 2 * sizeof(float); }      // [lanes][C][2] floats
 static int gn_det_check(const DetWs* det, int B, unsigned chunks) {
-  KDIP_REQUIRE(det->slab && det->cnt && det->ncnt >= B && (size_t)B * chunks * 64 * sizeof(double) <= det->slab_bytes,
-               "groupnorm: deterministic-reduction workspace too small (%d images x %u chunks, slab %zu bytes, %d counters)", B, chunks, det->slab_bytes, det->ncnt);
+  KDIP_REQUIRE(det->slab && (size_t)B * chunks * 64 * sizeof(double) <= det->slab_bytes,
+               "groupnorm: deterministic-reduction workspace too small (%d images x %u chunks, slab %zu bytes)", B, chunks, det->slab_bytes);
   return KDIP_OK;
 }
 int gn_stats(hipStream_t st, DType dt, const void* x, long ldx, int B, long HW, int C, double* stats, int prezeroed, const DetWs* det) {
@@ -140,17 +153,18 @@ int gn_stats(hipStream_t st, DType dt, const void* x, long ldx, int B, long HW, 
     KDIP_REQUIRE(C % 8 == 0 && C / 8 <= 1024, "groupnorm: unsupported C=%d", C);
     GnGeom g = gn_geom<bf16_t>(C);
     hipLaunchKernelGGL((gn_stats_kernel<bf16_t, false>), grid, dim3(g.nthreads), 0, st, (const bf16_t*)x, ldx, HW, C, g.VP,
-                       g.lanes, g.cpg, chunk, stats, nullptr, nullptr);
+                       g.lanes, g.cpg, chunk, stats, nullptr);
   } else {
     KDIP_REQUIRE(C / 4 <= 1024, "groupnorm: unsupported C=%d", C);
     GnGeom g = gn_geom<float>(C);
     if (det)
-      hipLaunchKernelGGL((gn_stats_kernel<float, true>), grid, dim3(g.nthreads), (size_t)g.lanes * C * 2 * sizeof(float), st, (const float*)x, ldx, HW, C, g.VP,
-                         g.lanes, g.cpg, chunk, stats, (double*)det->slab, det->cnt);
+      hipLaunchKernelGGL((gn_stats_kernel<float, true>), grid, dim3(g.nthreads), gn_det_lds(g.lanes, C), st, (const float*)x, ldx, HW, C, g.VP,
+                         g.lanes, g.cpg, chunk, stats, (double*)det->slab);
     else
       hipLaunchKernelGGL((gn_stats_kernel<float, false>), grid, dim3(g.nthreads), 0, st, (const float*)x, ldx, HW, C, g.VP,
-                         g.lanes, g.cpg, chunk, stats, nullptr, nullptr);
+                         g.lanes, g.cpg, chunk, stats, nullptr);
   }
+  if (det) hipLaunchKernelGGL(gn_det_finish_kernel, dim3(B), dim3(256), 0, st, (const double*)det->slab, (int)grid.x, stats);
   prof_end(st);
   KDIP_LAUNCH_CHECK();
   return KDIP_OK;
@@ -338,7 +352,7 @@ template <typename T, bool DET>
 __global__ void gn_bwd_stats_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy, long lddy,
                                     const float* __restrict__ coef, const float* __restrict__ mr, long HW, int C,
                                     int VP, int lanes, int cpg, long chunk, int silu, double* __restrict__ sums,
-                                    int half_lgW, double* det_slab, unsigned* det_cnt) {
+                                    int half_lgW, double* det_slab) {
   extern __shared__ __attribute__((aligned(16))) float gn_lsh[];      // DET: [lanes][C][2]
   // half_lgW >= 0: dy is a half-resolution tensor (adjoint of the 2x2 average pool, unet.py:236-240 backward):
   // dy(p) = 0.25 * dy_half[(y >> 1, x >> 1)], W = 1 << half_lgW, dy batch stride HW / 4
@@ -389,7 +403,7 @@ __global__ void gn_bwd_stats_kernel(const T* __restrict__ x, long ldx, const T* 
     }
   }
   if (DET) {       // (block-uniform)
-    gn_det_combine<EPV>(t1, t2, pl < lanes, vi, pl, lanes, C, cpg, gn_lsh, det_slab, det_cnt, sums);
+    gn_det_combine<EPV>(t1, t2, pl < lanes, vi, pl, lanes, C, cpg, gn_lsh, det_slab);
     return;
   }
   __syncthreads();
@@ -409,16 +423,17 @@ int gn_bwd_stats(hipStream_t st, DType dt, const void* x, long ldx, const void* 
   if (dt == DT_BF16) {
     GnGeom g = gn_geom<bf16_t>(C);
     hipLaunchKernelGGL((gn_bwd_stats_kernel<bf16_t, false>), grid, dim3(g.nthreads), 0, st, (const bf16_t*)x, ldx,
-                       (const bf16_t*)dy, lddy, coef, mr, HW, C, g.VP, g.lanes, g.cpg, chunk, silu, sums, half_lgW, nullptr, nullptr);
+                       (const bf16_t*)dy, lddy, coef, mr, HW, C, g.VP, g.lanes, g.cpg, chunk, silu, sums, half_lgW, nullptr);
   } else {
     GnGeom g = gn_geom<float>(C);
     if (det)
-      hipLaunchKernelGGL((gn_bwd_stats_kernel<float, true>), grid, dim3(g.nthreads), (size_t)g.lanes * C * 2 * sizeof(float), st, (const float*)x, ldx,
-                         (const float*)dy, lddy, coef, mr, HW, C, g.VP, g.lanes, g.cpg, chunk, silu, sums, half_lgW, (double*)det->slab, det->cnt);
+      hipLaunchKernelGGL((gn_bwd_stats_kernel<float, true>), grid, dim3(g.nthreads), gn_det_lds(g.lanes, C), st, (const float*)x, ldx,
+                         (const float*)dy, lddy, coef, mr, HW, C, g.VP, g.lanes, g.cpg, chunk, silu, sums, half_lgW, (double*)det->slab);
     else
       hipLaunchKernelGGL((gn_bwd_stats_kernel<float, false>), grid, dim3(g.nthreads), 0, st, (const float*)x, ldx,
-                         (const float*)dy, lddy, coef, mr, HW, C, g.VP, g.lanes, g.cpg, chunk, silu, sums, half_lgW, nullptr, nullptr);
+                         (const float*)dy, lddy, coef, mr, HW, C, g.VP, g.lanes, g.cpg, chunk, silu, sums, half_lgW, nullptr);
   }
+  if (det) hipLaunchKernelGGL(gn_det_finish_kernel, dim3(B), dim3(256), 0, st, (const double*)det->slab, (int)grid.x, sums);
   prof_end(st);
   KDIP_LAUNCH_CHECK();
   return KDIP_OK;

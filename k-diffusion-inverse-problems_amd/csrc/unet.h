@@ -81,11 +81,12 @@ struct UNet {
   Arena persist, scratch, zeros;     // zeros: fp64 statistics accumulators, cleared once per forward / VJP
   size_t zeros_fwd_end = 0;
   unsigned* x3_amax = nullptr;       // split-precision mode: bits of max |cotangent| of the current VJP (fp16 window of the dgrad convs' A operand)
+  unsigned* x3_sat = nullptr;        // split-precision mode: sticky device word, bit 0 = some conv launch staged an operand outside the fp16 window (kdip_unet_x3_saturated)
+  long x3_weight_sat = 0;            // ... weights of this handle outside the window at pack time
   int x3_window_per_launch = 0;      // 1: every dgrad launch takes its window from a sampled max |g| of its own input instead (kdip_unet_x3_window)
   // deterministic reductions (det.h): on for the fp32-storage modes (f32, bf16x3) -- GroupNorm statistics and split-K partial sums
   // are added in a fixed order, two runs of one call are bitwise equal; the bf16 throughput mode keeps floating-point atomics
   bool det = false;
-  unsigned* det_cnt = nullptr; int det_ncnt = 0;   // per-image arrival counters (zeros arena; zero between launches)
   float* sk_ws = nullptr; long sk_ws_floats = 0;   // split-K workspace of the small-spatial convs (zeros arena; kept zero by the finalize kernel)
   std::map<std::pair<const void*, int>, double*> fused_stats;   // (tensor, channels) -> GroupNorm sums already accumulated by its producer
   int ws_B = 0;                       // largest batch planned so far

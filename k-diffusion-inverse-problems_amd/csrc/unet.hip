@@ -169,6 +169,7 @@ int UNet::finalize() {
   KDIP_REQUIRE(!finalized, "unet already finalized");
   KDIP_HIP_CHECK(hipSetDevice(device));
   int rc = KDIP_OK;
+  const long x3_w0 = x3_weight_saturations();
   auto need = [&](const std::string& k, long numel) -> const float* {
     auto it = raw.find(k);
     if (it == raw.end()) { rc = set_error(KDIP_ERR_STATE, "missing parameter '%s'", k.c_str()); return nullptr; }
@@ -260,8 +261,10 @@ int UNet::finalize() {
   if (!rc && cdt == DT_F32X3) {
     const unsigned zero = 0;
     x3_amax = (unsigned*)upload(&zero, sizeof(zero));
+    x3_sat = (unsigned*)upload(&zero, sizeof(zero));
   }
   if (rc) return rc;
+  x3_weight_sat = x3_weight_saturations() - x3_w0;      // (packing of one handle runs on one host thread; concurrent finalizes may over-count, never under-count)
   raw.clear();
   finalized = true;
   return KDIP_OK;
@@ -284,7 +287,6 @@ double* new_sums(Ctx& c, int B) { return (double*)c.u->zeros.alloc(sizeof(double
 bool det_ws(Ctx& c, size_t slab_bytes, DetWs& w) {
   if (!c.u->det) return false;
   w.slab = c.u->scratch.alloc(slab_bytes); w.slab_bytes = slab_bytes;
-  w.cnt = c.u->det_cnt; w.ncnt = c.u->det_ncnt;
   return true;
 }
 size_t det_gn_bytes(int B, long HW) {      // gn_stats / gn_bwd_stats: [B][chunks][64] doubles, chunks <= max(1024 / B, HW / 256) + 1
@@ -432,8 +434,9 @@ int conv_f(Ctx& c, const ConvW& w, const void* x, long ldx, int B, int H, int W,
     if (det_ws(c, det_conv_bytes(B, H, W, w.cout), dw)) stt.det = &dw;
   }
   stt.sk_det = c.u->det ? 1 : 0;
+  stt.x3_sat = c.u->x3_sat;
   RUN(conv_forward(c.st, c.cdt(), w.ntaps, x, ldx, B, H, W, w.cin_pad, w.wf, w.bias, w.cout, y, ldy, res, ldr, out_f32, 1.f, w.cin,
-                   (stt.mode || in_ups || res_ups || tf_coef || stt.sk_det) ? &stt : nullptr, c.u->sk_ws, c.u->sk_ws_floats));
+                   (stt.mode || in_ups || res_ups || tf_coef || stt.sk_det || stt.x3_sat) ? &stt : nullptr, c.u->sk_ws, c.u->sk_ws_floats));
   return KDIP_OK;
 }
 // input-gradient: x here is dL/d(out) with >= cin_pad_b channels available (zero padded when cout % 32 != 0)
@@ -484,6 +487,7 @@ int conv_b(Ctx& c, const ConvW& w, const void* g, long ldg, int B, int H, int W,
     if (det_ws(c, det_conv_bytes(B, H, W, w.cin), dw)) stt.det = &dw;
   }
   stt.sk_det = c.u->det ? 1 : 0;
+  stt.x3_sat = c.u->x3_sat;
   RUN(conv_forward(c.st, c.cdt(), w.ntaps, g, ldg, B, H, W, w.cin_pad_b, w.wb, nullptr, w.cin, y, ldy, res, ldr, out_f32, 1.f, w.cout,
                    (stt.mode || stt.x3_amax || stt.sk_det) ? &stt : nullptr, c.u->sk_ws, c.u->sk_ws_floats));
   return KDIP_OK;
@@ -656,12 +660,9 @@ int UNet::forward_impl(hipStream_t st, const float* x_nchw, const float* t, int 
     upd(mid);
     for (auto& b : out) upd(b);
     if (det) {
-      // deterministic modes: one slab per K split, plain stores, nothing to keep zeroed (persist arena: lives through the VJP too);
-      // the arrival counters of the ordered reductions sit in the zeros arena (cleared here, kept zero by each launch's last block)
+      // deterministic modes: one slab per K split, plain stores, nothing to keep zeroed (persist arena: lives through the VJP too)
       sk_ws_floats = (long)B * 256 * maxc * 16;      // 16 = KDIP_SPLITK_MAX (conv.hip)
       sk_ws = (float*)persist.alloc(sizeof(float) * sk_ws_floats);
-      det_ncnt = B;
-      det_cnt = (unsigned*)zeros.alloc(sizeof(unsigned) * B);
     } else {
       sk_ws_floats = (long)B * 256 * maxc;
       sk_ws = (float*)zeros.alloc(sizeof(float) * sk_ws_floats);

@@ -38,6 +38,7 @@ class GraphedDenoiser:
         self.cg_margin = cg_margin
         self.cg_check = cg_check       # "each": poll the unconverged counter after every fixed-trip replay, redo + re-capture on a miss
         self.cg_trips = {}
+        self._cg_floor = {}            # key -> trips an earlier re-capture needed (kept across graph invalidations)
         self.cg_redone = 0             # fixed-trip replays that were not converged and were redone eagerly
         self._graphs = {}          # (sigma, shape) -> (graph, static_x, static_out)
         self.replays = 0
@@ -110,7 +111,8 @@ class GraphedDenoiser:
             if cg:      # the adaptive warm-up call told how many CG iterations this sigma needs: capture that many + a margin
                 op = self.den.operator
                 need = max([i for i in getattr(op, "cg_iters", [0]) if i >= 0] or [0])
-                trips = int(need * self.cg_margin) + 4
+                # (never fewer than an earlier re-capture of this sigma asked for, never more than the solver's own iteration cap)
+                trips = min(max(int(need * self.cg_margin) + 4, self._cg_floor.get(key, 0)), self.CG_MAXITER)
                 op.set_cg_fixed_trips(trips)
                 self.cg_trips[key] = trips
             g = torch.cuda.CUDAGraph()
@@ -143,8 +145,17 @@ class GraphedDenoiser:
             return out
         return so.clone()
 
+    CG_MAXITER = 1000                  # the mat-solvers' maxiter (condition/condition.py:343,379,432)
+
     def _recapture_cg(self, key, trips):
         g_old, sx, so_old = self._graphs.pop(key)
+        trips = min(max(trips, self.cg_trips.get(key, 0)), self.CG_MAXITER)
+        self._cg_floor[key] = trips                                   # survives an invalidation: a later first capture starts from here
+        if self._bindings() != self._bound:                           # the eager redo regrew a workspace: every other graph is stale
+            if self._graphs:
+                self.invalidations += 1
+            self._graphs.clear()
+            self._bound = self._bindings()
         op = self.den.operator
         ssig = sx.new_full([sx.shape[0]], float(key[0]))
         ssig._kdip_host_value = float(key[0])

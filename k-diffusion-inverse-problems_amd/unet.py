@@ -132,6 +132,15 @@ class UNetModel:
             raise ValueError("mode must be 'vjp' or 'launch'")
         L.check(self.lib.kdip_unet_x3_window(self._h, 1 if mode == "launch" else 0))
 
+    def x3_saturated(self, reset=True):
+        """dtype "bf16x3" only: flags of operands that left the fp16 window of the split-precision convs since the last reset (bit 0:
+        an activation / gradient operand in some launch, bit 1: a weight at pack time); 0 = every conv product carried its full
+        precision.  One stream synchronisation."""
+        import ctypes as C
+        f = C.c_int(0)
+        L.check(self.lib.kdip_unet_x3_saturated(self._h, L.stream(), 1 if reset else 0, C.byref(f)))
+        return int(f.value)
+
     def set_deterministic(self, on=True):
         """dtype "f32" / "bf16x3" only (default on): fixed-order cross-block reductions, two runs of one call are bitwise equal
         (csrc/det.h).  Off = the floating-point atomics of the bf16 mode (A/B timing).  Returns the previous setting."""

@@ -138,3 +138,30 @@ def test_x3_unet_with_wide_dynamic_range():
             ms["bf16x3"].forward_raw(x, t)
         print(f"                 ... per-launch window: bf16x3 {el:.2e}")
         assert el < 3e-5 and el < ev, (scale, el, ev)
+
+
+def test_x3_saturation_flag():
+    """The fp16 window of the split-precision convs is watched: `x3_saturated()` stays 0 while every staged operand (after its power-of-two
+    scaling) is inside +-65504 -- i.e. every product carried its full precision -- and bit 0 is set by the launch that stages one outside
+    (here: a forward whose input is scaled by 1e7, so the first conv's activations leave the window); bit 1 reports weights outside the
+    window at pack time (|w| > 255.9)."""
+    import kdip_amd.unet as ku
+    from oracle import unet as ounet
+    cfg = ounet.UNetConfig(**ounet.TINY)
+    sd = ounet.init_state_dict(cfg, seed=0)
+    kw = dict(image_size=64, model_channels=32, num_res_blocks=1, attention_resolutions="32", channel_mult=(1, 2))
+    m = ku.UNetModel(dtype="bf16x3", **kw)
+    m.load_state_dict(sd)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 3, 64, 64, generator=g).cuda()
+    t = torch.tensor([100.0, 700.0]).cuda()
+    m.forward_raw(x, t)
+    m.vjp(torch.randn(2, 6, 64, 64, generator=g).cuda() * 1e-4)
+    assert m.x3_saturated() == 0
+    m.forward_raw(x * 1e7, t)
+    assert m.x3_saturated() & 1
+    assert m.x3_saturated() == 0                     # (the query reset it)
+    big = {k: (v * 1e4 if k == "input_blocks.0.0.weight" else v) for k, v in sd.items()}
+    m2 = ku.UNetModel(dtype="bf16x3", **kw)
+    m2.load_state_dict(big)
+    assert m2.x3_saturated() & 2
