@@ -428,7 +428,10 @@ def main():
         pmc = next((f for f in (os.path.join(ROOT, "profiles", t + ".json") for t in cands) if os.path.exists(f)), "")
         if pmc:
             try:
-                e = json.load(open(pmc))["shapes"].get("|".join(key[1:]))
+                shapes_, base_ = json.load(open(pmc))["shapes"], "|".join(key[1:])
+                # (first-generation kernel: the PMC file keys one entry per template instantiation, "<tag|shape>|<template arguments>")
+                cand_ = [v for k_, v in shapes_.items() if k_ == base_ or k_.startswith(base_ + "|")]
+                e = max(cand_, key=lambda v: v.get("launches_per_pass", 0) * v.get("mean_launch_us_under_pmc", 0)) if cand_ else None
                 if e:
                     traffic = e.get("hbm_bytes_per_launch")
                     traffic_source = ("profiles/" + os.path.basename(pmc) + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the in-network launches "

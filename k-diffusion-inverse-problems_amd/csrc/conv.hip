@@ -173,10 +173,13 @@ int conv_debug_timing(void* buf, int H, int cin, int cout, int st_mode) {
 
 constexpr int KC = 32;            // input channels per B-pipeline stage (one tap of one 32-channel sub-chunk); padding granule of Cin
 #ifndef KDIP_X3_KC
-#define KDIP_X3_KC 32             // split-precision 3x3 instantiations: channels per LDS stage.  16 = one k-step per stage: the operand queues (3 A planes + 2 B planes
-#endif                            // per fragment) of a 32-channel stage do not fit the register file next to the accumulators (hipcc then re-reads fragments right before use)
-// channels per sub-chunk of an instantiation
-template <typename T, int NTAPS> constexpr int kc_of() { return (std::is_same<T, f32x3_t>::value && NTAPS == 9) ? KDIP_X3_KC : KC; }
+#define KDIP_X3_KC 16             // split-precision 3x3, 128x128 tile: channels per LDS stage.  16 = one k-step per stage: 191 instead of 256 VGPRs and 41 instead of 77 KB of
+#endif                            // LDS per block, which is what lets THREE blocks share a CU (KDIP_X3_OCC 3): a block spends 19 % of its life in its prologue / epilogue
+                                  // (tools/conv_phases.py: 6.9 + 2.8 of 49.8 us), and with two blocks per CU the MFMA pipe idles through much of that.  Measured (bench, 20
+                                  // steps, interleaved): KC 16 alone +-0; KC 16 + 3 blocks per CU 101.6 -> 97.8 ms per step, 128 -> 128 @ 256^2 509 -> 488 us.  The narrower
+                                  // tiles (128x64 / 128x32: small maps) keep 32-channel stages (16: 6.7 -> 7.0 ms per step for the 128x64 class).
+// channels per sub-chunk of an instantiation (TILE = MT * NT accumulator tiles per wave)
+template <typename T, int NTAPS, int TILE> constexpr int kc_of() { return (std::is_same<T, f32x3_t>::value && NTAPS == 9 && TILE == 4) ? KDIP_X3_KC : KC; }
 #ifndef KDIP_CONV1_NT_LOAD
 #define KDIP_CONV1_NT_LOAD 0     // non-temporal input staging loads of the 1x1 convs: big-map class -3 %, small-map classes +2-4 %, step unchanged
 #endif
@@ -246,7 +249,7 @@ template <typename T, int NTAPS> constexpr int kc_of() { return (std::is_same<T,
 #define KDIP_OCC 3
 #endif
 #ifndef KDIP_X3_OCC
-#define KDIP_X3_OCC 2        // split-precision 128x128 tiles: resident blocks per CU the register budget is set for
+#define KDIP_X3_OCC 3        // split-precision 128x128 tiles: resident blocks per CU the register budget is set for (3 needs KDIP_X3_KC 16: LDS)
 #endif
 #ifndef KDIP_ROWPAD
 #define KDIP_ROWPAD 1        // 256-byte-multiple LDS row pitch of the 16-pixel-wide 3x3 patches (conflict-free fragment reads; 0: natural pitch, A/B builds)
@@ -631,7 +634,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
   constexpr int BM = WAVES_M * MT * 32;
   constexpr int BN = WAVES_N * NT * 32;
   constexpr int KSTEP = Mma<T>::KSTEP;
-  constexpr int KC = kc_of<T, NTAPS>();                // (shadows the namespace constant: this instantiation's sub-chunk width)
+  constexpr int KC = kc_of<T, NTAPS, MT * NT>();       // (shadows the namespace constant: this instantiation's sub-chunk width)
   constexpr int KS = KC / KSTEP;                       // k-steps per sub-chunk
   constexpr int KCH = KC * SUBS;                       // channels per LDS stage
   constexpr int PIXB = KCH * Mma<T>::LDS_BPC + 16;     // padded LDS pixel stride (bytes)
@@ -1218,7 +1221,7 @@ __global__ void conv_splitk_finalize_kernel(float* __restrict__ ws, const float*
 template <typename T, int NTAPS, int WAVES_M, int WAVES_N, int MT, int NT, int SUBS>
 static int launch_cfg2(ConvParams& p, hipStream_t st) {
   constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32;
-  constexpr int KC = kc_of<T, NTAPS>();
+  constexpr int KC = kc_of<T, NTAPS, MT * NT>();
   constexpr int PIXB = KC * SUBS * Mma<T>::LDS_BPC + 16;
   constexpr int HALO = (NTAPS == 9) ? 1 : 0;
   // 32-pixel-wide patches: an MFMA m-tile (32 rows) is one patch row, so the 16-lane groups of

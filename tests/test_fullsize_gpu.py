@@ -33,35 +33,55 @@ def _setup(cfg_name, op_name, dtype, B=1, out_cov=False):
     return m, sd, ocfg, hop, oop, meas, x0
 
 
+def _oracle_with_hip_mask(oden, hip_raw, x, sigma):
+    """Oracle guided call with the HIP run's clamp-gradient mask imposed (pixels with |x0_raw| = 1 to within rounding have two correct
+    answers: test_imagenet_motion_typeI_analytic_fullsize).  The HIP parity modes are deterministic, so the set of such pixels is FIXED for a
+    given build and input; it is returned (and printed by the callers) as a reviewable list, and bounded: <= 4 pixels, each within 1e-4
+    of the boundary."""
+    oden.clamp_mask_override = hip_raw.abs() <= 1
+    ref = oden(x, sigma)
+    flips = (oden.last_x0_raw.abs() <= 1) != oden.clamp_mask_override
+    idx = flips.nonzero().tolist()
+    assert len(idx) <= 4 and (not idx or float((oden.last_x0_raw[flips].abs() - 1).abs().max()) < 1e-4), idx
+    return ref, [(tuple(i), float(oden.last_x0_raw[tuple(i)])) for i in idx]
+
+
 @pytest.mark.parametrize("sigma_v", [1.5, 0.12])
 def test_ffhq_type1_convert_fullsize(sigma_v):
-    """BASELINE configs[1] shape at batch 1: f32 mode within 2e-3 max-abs of the oracle (incl. CG
-    branch at sigma 0.12); bf16 mode reported as PSNR."""
+    """BASELINE configs[1] -- the benchmarked configuration -- at 256 x 256, batch 1, one closed-form call (sigma 1.5) and one CG-branch
+    call (sigma 0.12) against the CPU oracle: f32 AND bf16x3 (the headline arithmetic of bench.py) within 2e-4 max-abs; bf16 reported as
+    PSNR with a measured floor.  (condition/condition.py:167-174,231-248,351-386)"""
     import kdip_amd.unet as ku
     import kdip_amd.condition as kc
     from oracle import condition as ocond
     m, sd, ocfg, hop, oop, meas, x0 = _setup("FFHQ", "gaussian_blur", "f32")
     x = x0 + sigma_v * torch.randn(1, 3, 256, 256, generator=torch.Generator().manual_seed(11))
     D = ku.GaussianDiffusionTables()
-    hm = kc.ConditionOpenAIDenoiser(inner_model=m, diffusion=D, x0_cov_type="convert", recon_mse=None, operator=hop,
-                                    measurement=(meas[0].cuda(), meas[1].cuda()), guidance="I", device="cuda")
-    hat = hm(x.cuda(), torch.tensor([sigma_v], device="cuda")).cpu()
-    # the oracle takes the HIP path's clamp-gradient mask (see test_imagenet_motion_typeI_analytic_fullsize: pixels with
-    # |x0_raw| = 1 to within rounding have two correct answers); the masks may only disagree at such borderline pixels
+    measd = (meas[0].cuda(), meas[1].cuda())
     oden = ocond.GuidedDenoiser(sd, ocfg, oop, meas, "I", x0_cov_type="convert")
-    oden.clamp_mask_override = hm._stash[0].cpu().abs() <= 1
-    ref = oden(x, torch.tensor([sigma_v]))
-    flips = (oden.last_x0_raw.abs() <= 1) != oden.clamp_mask_override
-    assert int(flips.sum()) <= 4 and (not flips.any() or float((oden.last_x0_raw[flips].abs() - 1).abs().max()) < 1e-4)
-    err = float((hat - ref).abs().max())
-    assert err < 2e-3, err
+    errs, ref32 = {}, None
+    for dtype in ("f32", "bf16x3"):
+        if dtype != "f32":
+            del m, hm
+            torch.cuda.empty_cache()
+            m = ku.UNetModel(dtype=dtype, **ku.FFHQ_CONFIG); m.load_state_dict(sd)
+        hm = kc.ConditionOpenAIDenoiser(inner_model=m, diffusion=D, x0_cov_type="convert", recon_mse=None, operator=hop,
+                                        measurement=measd, guidance="I", device="cuda")
+        hat = hm(x.cuda(), torch.tensor([sigma_v], device="cuda")).cpu()
+        ref, flips = _oracle_with_hip_mask(oden, hm._stash[0].cpu(), x, torch.tensor([sigma_v]))
+        errs[dtype] = float((hat - ref).abs().max())
+        print(f"\nFFHQ configs[1] full-size sigma={sigma_v} {dtype}: max-abs {errs[dtype]:.2e}; borderline clamp pixels {flips}")
+        if dtype == "f32":
+            ref32 = ref
+    assert errs["f32"] < 2e-4 and errs["bf16x3"] < 2e-4, errs          # measured <= 7.6e-5
     del m, hm
+    torch.cuda.empty_cache()
     m2 = ku.UNetModel(dtype="bf16", **ku.FFHQ_CONFIG); m2.load_state_dict(sd)
     hm2 = kc.ConditionOpenAIDenoiser(inner_model=m2, diffusion=D, x0_cov_type="convert", recon_mse=None, operator=hop,
-                                     measurement=(meas[0].cuda(), meas[1].cuda()), guidance="I", device="cuda")
+                                     measurement=measd, guidance="I", device="cuda")
     hat2 = hm2(x.cuda(), torch.tensor([sigma_v], device="cuda")).cpu()
-    p = psnr_db(hat2, ref)
-    print(f"\nFFHQ full-size sigma={sigma_v}: f32 max-abs {err:.2e}; bf16 PSNR(hip, oracle) {p:.1f} dB")
+    p = psnr_db(hat2, ref32)
+    print(f"FFHQ full-size sigma={sigma_v}: bf16 PSNR(hip, oracle) {p:.1f} dB")
     assert p > (30.0 if sigma_v > 1 else 64.0)      # measured 35.2 / 69.5 dB: floor = measured - 5 dB
 
 
@@ -284,7 +304,7 @@ def test_e2e_teacher_forced(opn, guid, cov, extra):
       bf16x3: max-abs <= 2e-4 on every call (the bound of the full-size oracle comparisons above).  The guided output is discontinuous
               where |x0_raw| crosses 1 (VJP through clamp, condition.py:231), so calls whose clamp mask differs from the teacher's are
               re-evaluated with the teacher's mask imposed (stepwise path) after checking that the masks differ only at pixels within
-              1e-4 of the boundary.
+              1e-4 x max(1, sigma / 5) of the boundary.
       bf16:   per-call PSNR(bf16, f32) floors, stated above.
     Recorded in gpurun_out/e2e_teacher_forced.jsonl."""
     import json, os
@@ -324,7 +344,9 @@ def test_e2e_teacher_forced(opn, guid, cov, extra):
                 nd = int(differ.sum())
                 if nd:
                     dist = float((raw_t[differ].abs() - 1).abs().max())
-                    assert nd <= 64 and dist < 1e-4, (opn, s, nd, dist)      # only borderline pixels may flip
+                    # only borderline pixels may flip.  x0_raw = a_t x c_in - b_t eps with b_t ~ sigma: an error of the UNet output (~5e-6 of its
+                    # scale) moves x0_raw by ~sigma times that, so "borderline" is 1e-4 up to sigma 5 and 2e-5 sigma above (measured: 1.9e-4 at sigma 46)
+                    assert nd <= 64 and dist < 1e-4 * max(1.0, 0.2 * s), (opn, s, nd, dist)
                     flips_total += nd
                     forced_calls += 1
                     out = _forced_mask_call(den, x, sv, raw_t)

@@ -1,6 +1,6 @@
 """Per-block phase times of one conv layer shape inside a real guided Heun step (needs a -DKDIP_TIMING=1 build:
 python k-diffusion-inverse-problems_amd/build.py --variant timing -DKDIP_TIMING=1; KDIP_LIB_PATH=...libkdip_hip_timing.so).
-usage: python tools/conv_phases.py H cin cout st_mode [batch]"""
+usage: python tools/conv_phases.py H cin cout st_mode [batch] [dtype bf16|bf16x3|f32]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
@@ -8,8 +8,9 @@ import kdip_amd._lib as L
 import kdip_amd.unet as ku, kdip_amd.condition as kc, kdip_amd.measurements as km, kdip_amd.sampling as ks
 H, cin, cout, mode = [int(a) for a in sys.argv[1:5]]
 B = int(sys.argv[5]) if len(sys.argv) > 5 else 16
+DT = sys.argv[6] if len(sys.argv) > 6 else "bf16"
 lib = L.load()
-model = ku.UNetModel(dtype="bf16", **ku.FFHQ_CONFIG); model.load_state_dict(ku.synthetic_state_dict(seed=0, **ku.FFHQ_CONFIG))
+model = ku.UNetModel(dtype=DT, **ku.FFHQ_CONFIG); model.load_state_dict(ku.synthetic_state_dict(seed=0, **ku.FFHQ_CONFIG))
 D = ku.GaussianDiffusionTables()
 op = km.get_operator("gaussian_blur", device="cuda", in_shape=(1, 3, 256, 256), kernel_size=61, intensity=3.0, sigma_s=0.05)
 x0 = bench.smooth_image(B, 256, 1).cuda(); torch.manual_seed(2); meas = op.forward(x0.clone(), flatten=True)

@@ -4,7 +4,10 @@ HBM bytes follow MI355X_MICROARCH.md: FETCH_SIZE (KiB) x 2 on gfx950 for wide co
 import csv, glob, json, os, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 O = os.path.join(ROOT, "gpurun_out", "pmcnet")
-TAG = os.environ.get("PMC_TAG", "r03")          # round tag of the output file: profiles/<TAG>_pmc_innetwork.json
+TAG = os.environ.get("PMC_TAG", "r03")          # round tag of the output file: profiles/<TAG>_pmc_innetwork[_<dtype>].json
+DT = os.environ.get("PMC_DTYPE", "bf16")        # bf16: the conv3 kernels (records tagged conv3*); bf16x3 / f32: every conv_igemm_kernel launch (class conv*)
+KSUB = "conv3_kernel" if DT == "bf16" else "conv_igemm_kernel"
+SUFFIX = "" if DT == "bf16" else "_" + DT
 shapes = collections.defaultdict(lambda: collections.defaultdict(list))
 meta = {}
 for d in "abcde":
@@ -12,16 +15,19 @@ for d in "abcde":
     files = glob.glob(os.path.join(O, d, "**", "*counter_collection.csv"), recursive=True)
     if not os.path.exists(dump) or not files:
         continue
-    recs = [r for r in csv.DictReader(open(dump)) if r["tag"].startswith("conv3")]
+    recs = [r for r in csv.DictReader(open(dump)) if (r["tag"].startswith("conv3") if DT == "bf16" else r["class"].startswith("conv"))]
     disp = collections.OrderedDict()
     for f in files:
         for r in csv.DictReader(open(f)):
-            if "conv3_kernel" in r["Kernel_Name"]:
+            if KSUB in r["Kernel_Name"]:
                 disp.setdefault(int(r["Dispatch_Id"]), []).append(r)
     ids = sorted(disp)
     assert len(ids) == len(recs), (d, len(ids), len(recs))
     for did, rec in zip(ids, recs):
         key = "|".join((rec["tag"], rec["d0"], rec["d1"], rec["d2"], rec["d3"]))
+        if DT != "bf16":     # one tag ("conv") for every launch of the first-generation kernel: tell the instantiations apart by their template arguments
+            kn = rows0 = disp[did][0]["Kernel_Name"]
+            key += "|" + kn[kn.find("<") + 1:kn.rfind(">")].replace("kdip::", "").replace(" ", "")
         meta[key] = rec
         rows = disp[did]
         for r in rows:
@@ -55,7 +61,7 @@ for key, c in shapes.items():
         e["sq_active_inst_any_frac"] = m["SQ_ACTIVE_INST_ANY"] / m["SQ_WAVE_CYCLES"]
     e["vgpr_alloc"] = m.get("_vgpr")
     out["shapes"][key] = e
-json.dump(out, open(os.path.join(ROOT, "profiles", f"{TAG}_pmc_innetwork.json"), "w"), indent=1)
-json.dump(out, open(os.path.join(O, f"{TAG}_pmc_innetwork.json"), "w"), indent=1)      # (gpurun merges only gpurun_out/ back: copy this one into profiles/)
+json.dump(out, open(os.path.join(ROOT, "profiles", f"{TAG}_pmc_innetwork{SUFFIX}.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(O, f"{TAG}_pmc_innetwork{SUFFIX}.json"), "w"), indent=1)      # (gpurun merges only gpurun_out/ back: copy this one into profiles/)
 for k, e in sorted(out["shapes"].items(), key=lambda kv: -kv[1]["mean_launch_us_under_pmc"] * kv[1]["launches_per_pass"])[:12]:
     print(k, {a: (round(b, 3) if isinstance(b, float) else b) for a, b in e.items() if a in ("launches_per_pass", "mean_launch_us_under_pmc", "traffic_over_algorithmic", "mfma_busy_frac", "lds_bank_conflict_frac_of_lds_active", "l2_hit_rate", "shader_clock_ghz")})

@@ -1,6 +1,6 @@
 """One guided Heun step of the bench workload (BASELINE configs[1], one part-batch of 8 images, one stream) with the library's
 launch profiler on from the very first launch, so that the n-th conv3 record of the dump is the n-th conv3 dispatch of the
-process -- tools/pmc_join.py joins it with a `rocprofv3 --pmc` pass of this same command.  usage: python tools/pmc_step.py dump.csv [batch]"""
+process -- tools/pmc_join.py joins it with a `rocprofv3 --pmc` pass of this same command.  usage: python tools/pmc_step.py dump.csv [batch] [dtype]"""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,12 +9,13 @@ import kdip_amd.unet as ku, kdip_amd.condition as kc, kdip_amd.measurements as k
 from bench import smooth_image
 dump = sys.argv[1]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+DT = sys.argv[3] if len(sys.argv) > 3 else os.environ.get("PMC_DTYPE", "bf16")
 lib = L.load()
 L.check(lib.kdip_profile_enable(1))
 dev = "cuda"
 D = ku.GaussianDiffusionTables()
 sig = ks.get_sigmas_karras(100, 0.01, 80, rho=7.0, device=dev).cpu()
-model = ku.UNetModel(dtype="bf16", device=dev, **ku.FFHQ_CONFIG)
+model = ku.UNetModel(dtype=DT, device=dev, **ku.FFHQ_CONFIG)
 model.load_state_dict(ku.synthetic_state_dict(seed=0, **ku.FFHQ_CONFIG))
 op = km.get_operator("gaussian_blur", device=dev, in_shape=(1, 3, 256, 256), kernel_size=61, intensity=3.0, sigma_s=0.05)
 x0 = smooth_image(B, 256, 1).to(dev)
