@@ -349,6 +349,12 @@ def main():
         "ranks": topo["ranks"], "distinct_devices": topo["distinct_devices"], "backend": topo["backend"], "devices": topo["devices"],
         "gather_ms": round(gather_ms, 3), "gather_bytes_per_rank": B * 3 * S * S * 4,
     }
+    if args.dtype == "bf16x3":      # every conv product of the timed region carried its full split precision (no operand left the fp16 window of the tail planes)
+        sat = 0
+        for pt in parts:
+            with torch.cuda.stream(pt["stream"]):
+                sat |= pt["den"].inner_model.x3_saturated()
+        out["x3_saturated"] = sat       # 0 = every product of every conv kept its full split precision (kdip_unet_x3_saturated)
     pw = sampler.summary() if sampler else None
     if pw:
         out["power"] = pw

@@ -253,6 +253,11 @@ __global__ void resize_axis_adj_kernel(const float* __restrict__ g, const float*
     const float* gp = g + p * (long)n_out * other;
     float s = 0.f;
     for (int o = 0; o < n_out; ++o) {
+      // the field of view of output o is a run of consecutive input indices, folded back at the borders (mirror padding): away from
+      // the borders [first tap, last tap] bounds it and most outputs are skipped after two loads
+      const int f0 = fov[o * taps], f1 = fov[o * taps + taps - 1];
+      const int lo = f0 < f1 ? f0 : f1, hi = f0 < f1 ? f1 : f0;
+      if (lo >= taps && hi < n_in - taps && (src < lo || src > hi)) continue;
       const float gv = (axis == 1) ? gp[(long)q * n_out + o] : gp[(long)o * other + q];
       for (int t = 0; t < taps; ++t)
         if (fov[o * taps + t] == src) s += gv * w[o * taps + t];

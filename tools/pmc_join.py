@@ -3,7 +3,7 @@ per (conv3 fusion mode, layer shape) mean counters of the in-network launches ->
 HBM bytes follow MI355X_MICROARCH.md: FETCH_SIZE (KiB) x 2 on gfx950 for wide coalesced reads; WRITE_SIZE (KiB) as reported."""
 import csv, glob, json, os, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-O = os.path.join(ROOT, "gpurun_out", "pmcnet")
+O = os.environ.get("PMC_DIR") or os.path.join(ROOT, "gpurun_out", "pmcnet")      # PMC_DIR: re-join a saved set of passes
 TAG = os.environ.get("PMC_TAG", "r03")          # round tag of the output file: profiles/<TAG>_pmc_innetwork[_<dtype>].json
 DT = os.environ.get("PMC_DTYPE", "bf16")        # bf16: the conv3 kernels (records tagged conv3*); bf16x3 / f32: every conv_igemm_kernel launch (class conv*)
 KSUB = "conv3_kernel" if DT == "bf16" else "conv_igemm_kernel"
@@ -46,7 +46,12 @@ for key, c in shapes.items():
     e["mean_launch_us_under_pmc"] = sum(durs) / len(durs)
     if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
         e["FETCH_SIZE_KiB_raw"] = m["FETCH_SIZE"]; e["WRITE_SIZE_KiB_raw"] = m["WRITE_SIZE"]
-        e["hbm_bytes_per_launch"] = m["FETCH_SIZE"] * 1024 * 2 + m["WRITE_SIZE"] * 1024
+        # gfx950: FETCH_SIZE = read requests x 64 B; a wide coalesced read (>= 128 contiguous bytes per pixel row) issues 128-byte requests
+        # that are tallied at 64 B -> x 2 (MI355X_MICROARCH.md, HBM).  The split-precision 128 x 128-tile 3x3 kernel stages 16 channels
+        # = 64 contiguous bytes per pixel per chunk: its requests ARE 64 bytes, no doubling.
+        narrow = DT != "bf16" and "|f32x3_t,9,2,2,2,2," in key
+        e["fetch_bytes_per_request_assumed"] = 64 if narrow else 128
+        e["hbm_bytes_per_launch"] = m["FETCH_SIZE"] * 1024 * (1 if narrow else 2) + m["WRITE_SIZE"] * 1024
         e["traffic_over_algorithmic"] = e["hbm_bytes_per_launch"] / e["algorithmic_bytes"]
     if "SQ_VALU_MFMA_BUSY_CYCLES" in m and "GRBM_GUI_ACTIVE" in m:
         # SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs
