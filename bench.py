@@ -204,6 +204,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="images per GPU (BASELINE configs[1]: 16)")
     ap.add_argument("--no-large-batch", action="store_true", help="skip the extra throughput leg at batch 128 (N = 1 only)")
     ap.add_argument("--streams", type=int, default=2, help="part-batches per GPU, each on its own HIP stream + host thread")
+    ap.add_argument("--stagger-ms", type=float, default=0.0, help="start part-batch k of a GPU k x this many milliseconds after part 0 (phase offset between the streams; inside the timed region)")
     ap.add_argument("--cu-split", action="store_true", help="give each part-batch stream its own share of the compute units (CU-masked HIP streams)")
     ap.add_argument("--dtype", choices=("bf16", "f32", "bf16x3"), default="bf16x3",
                     help="UNet arithmetic: bf16x3 (default) = fp32 storage + split-precision convs, the fast mode that meets north_star's 1e-3 dB against the "
@@ -293,7 +294,8 @@ def main():
 
     def run_all(parts, steps, chain):
         from kdip_amd.evaluation import run_on_streams
-        outs = run_on_streams([lambda pt=pt: run_part(pt, steps, chain) for pt in parts], [pt["stream"] for pt in parts], dev)
+        outs = run_on_streams([lambda pt=pt: run_part(pt, steps, chain) for pt in parts], [pt["stream"] for pt in parts], dev,
+                              delays=[k * args.stagger_ms * 1e-3 for k in range(len(parts))] if args.stagger_ms > 0 else None)
         torch.cuda.synchronize()
         return torch.cat(outs)
 

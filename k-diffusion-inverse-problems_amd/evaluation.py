@@ -122,13 +122,18 @@ def psnr(hat_x0, x0):
     return 10 * torch.log10(1.0 / mse)
 
 
-def run_on_streams(fns, streams=None, device=None):
+def run_on_streams(fns, streams=None, device=None, delays=None):
     """Run the callables `fns[k]()` concurrently, each inside its own HIP stream context on its own host thread, and return
     their results in order (exceptions are re-raised).  Independent part-batches driven this way overlap one part's
     HBM-bound passes and host-side convergence waits with another part's MFMA-bound convs (bench.py --streams,
     sample_condition.py --streams).  Every callable must use its own UNet handle and operator context: library handles
-    are per (thread, stream), never shared."""
+    are per (thread, stream), never shared.
+    `delays[k]` (seconds, optional): callable k starts that much later -- a phase offset between the part-batches: the UNet runs its
+    large maps (chip-filling convs) at both ends of a pass and its small maps (latency-bound launches) in the middle, and two streams in
+    lockstep are in the same phase at the same time; offset by a fraction of a call, one part's small-map launches run beside the other's
+    large-map convs."""
     import threading
+    import time
     n = len(fns)
     if n == 1:
         return [fns[0]()]
@@ -139,6 +144,8 @@ def run_on_streams(fns, streams=None, device=None):
     def work(k):
         try:
             torch.cuda.set_device(device)
+            if delays is not None and delays[k] > 0:
+                time.sleep(delays[k])
             with torch.cuda.stream(streams[k]):
                 res[k] = fns[k]()
         except BaseException as e:
