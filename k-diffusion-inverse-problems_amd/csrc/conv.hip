@@ -251,6 +251,11 @@ template <typename T, int NTAPS, int TILE> constexpr int kc_of() { return (std::
 #ifndef KDIP_X3_OCC
 #define KDIP_X3_OCC 3        // split-precision 128x128 tiles: resident blocks per CU the register budget is set for (3 needs KDIP_X3_KC 16: LDS)
 #endif
+#ifndef KDIP_EPI32_FOLD2
+#define KDIP_EPI32_FOLD2 0   // fp32-storage epilogue, GroupNorm-backward sums: 1 = taken in the store sweep from prefetched GroupNorm-input rows instead of the second
+                             // sweep (13.9 vs 2.8 us of epilogue per block).  Measured (bench, interleaved): 98.4 vs 96.0 ms per step -- the silu' chains and 32 more
+                             // live registers beside the accumulators cost more than the sweep's four dependent load batches.  Off.
+#endif
 #ifndef KDIP_ROWPAD
 #define KDIP_ROWPAD 1        // 256-byte-multiple LDS row pitch of the 16-pixel-wide 3x3 patches (conflict-free fragment reads; 0: natural pitch, A/B builds)
 #endif
@@ -542,6 +547,18 @@ __device__ __forceinline__ void epilogue_f32_fast(const ConvParams& p, f32x16 (&
   float bv[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) bv[nt] = p.bias ? p.bias[(nt0 + nt) * 32 + (lane & 31)] : 0.f;
+  // MODE 2, folded (KDIP_EPI32_FOLD2): the GroupNorm-input rows of an m-tile are requested with its pixel addresses, ahead of the transpose
+  // (as the residual rows are), and the backward sums are taken from the output values while they are in registers -- no second sweep
+  // that re-reads dy and waits for x in four dependent batches (13.9 vs 2.8 us of epilogue per block, tools/conv_phases.py)
+  constexpr bool FOLD2 = MODE == 2 && KDIP_EPI32_FOLD2;
+  float ca[4] = {0.f, 0.f, 0.f, 0.f}, cb[4] = {0.f, 0.f, 0.f, 0.f};
+  float2 mrv = make_float2(0.f, 0.f);
+  if (FOLD2) {
+    const float4* cf = (const float4*)(p.st_coef + ((long)img0 * p.Cout + nl) * 2);
+    const float4 c0 = cf[0], c1 = cf[1];
+    ca[0] = c0.x; ca[1] = c0.z; ca[2] = c1.x; ca[3] = c1.z; cb[0] = c0.y; cb[1] = c0.w; cb[2] = c1.y; cb[3] = c1.w;
+    mrv = *(const float2*)(p.st_mr + ((long)img0 * 32 + nl / cpg) * 2);
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     int pix[NPASS];
@@ -555,6 +572,8 @@ __device__ __forceinline__ void epilogue_f32_fast(const ConvParams& p, f32x16 (&
       if (RES) {
         const int rp = p.res_ups ? ((img0 + tb) * (p.H >> 1) + ((y0 + ty) >> 1)) * (p.W >> 1) + ((x0 + tx) >> 1) : pix[it];
         rres[it] = *(const float4*)(res + (long)rp * p.ldr + nl);
+      } else if (FOLD2) {
+        rres[it] = *(const float4*)(sx + (long)pix[it] * p.st_ldx + nl);
       }
     }
 #pragma unroll
@@ -575,16 +594,29 @@ __device__ __forceinline__ void epilogue_f32_fast(const ConvParams& p, f32x16 (&
         s1 += (v.x + v.y) + (v.z + v.w);
         s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
       }
+      if (FOLD2 && !RES) {
+        const float vv[4] = {v.x, v.y, v.z, v.w}, xv[4] = {rres[it].x, rres[it].y, rres[it].z, rres[it].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float z = ca[e] * xv[e] + cb[e];
+          const float dz = p.st_silu ? vv[e] * silu_grad_f(z) : vv[e];
+          const float adz = ca[e] * dz;
+          s1 += adz;
+          s2 += adz * (xv[e] - mrv.x) * mrv.y;
+        }
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
-  if (MODE == 2) {
+  if (MODE == 2 && !(FOLD2 && !RES)) {
     // GroupNorm-backward sums in a second sweep, once the accumulators are dead: every lane re-reads exactly the dy values it
     // stored itself (program order, L2-hot) next to the x rows, 4 passes per batch in flight
-    const float4* cf = (const float4*)(p.st_coef + ((long)img0 * p.Cout + nl) * 2);
-    const float4 c0 = cf[0], c1 = cf[1];
-    const float ca[4] = {c0.x, c0.z, c1.x, c1.z}, cb[4] = {c0.y, c0.w, c1.y, c1.w};
-    const float2 mrv = *(const float2*)(p.st_mr + ((long)img0 * 32 + nl / cpg) * 2);
+    {
+      const float4* cf = (const float4*)(p.st_coef + ((long)img0 * p.Cout + nl) * 2);
+      const float4 c0 = cf[0], c1 = cf[1];
+      ca[0] = c0.x; ca[1] = c0.z; ca[2] = c1.x; ca[3] = c1.z; cb[0] = c0.y; cb[1] = c0.w; cb[2] = c1.y; cb[3] = c1.w;
+      mrv = *(const float2*)(p.st_mr + ((long)img0 * 32 + nl / cpg) * 2);
+    }
     constexpr int SB = (MT * NPASS) % 4 == 0 ? 4 : 2;
 #pragma unroll 1
     for (int q0 = 0; q0 < MT * NPASS; q0 += SB) {

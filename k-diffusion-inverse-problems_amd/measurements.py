@@ -273,6 +273,26 @@ def cubic_resize_tables(n_in, n_out, scale):
     return np.ascontiguousarray(wts[:, keep].astype(np.float32)), np.ascontiguousarray(src[:, keep].astype(np.int32))
 
 
+def transpose_resize_tables(w, f, n_in):
+    """Tables of the ADJOINT of a resize axis as another gather: for every input index `src` the (output o, weight) pairs whose field
+    of view contains it, in (o, tap) order, padded to the longest list with weight 0 -- the adjoint then runs on the forward kernel
+    (kdip_resize_axis with n_in and n_out exchanged): coalesced, no atomics, a fixed summation order."""
+    n_out, taps = w.shape
+    lists = [[] for _ in range(n_in)]
+    for o in range(n_out):
+        for t in range(taps):
+            if w[o, t] != 0.0:
+                lists[int(f[o, t])].append((o, float(w[o, t])))
+    tmax = max(1, max(len(l) for l in lists))
+    wt = np.zeros((n_in, tmax), np.float32)
+    ft = np.zeros((n_in, tmax), np.int32)
+    for src, l in enumerate(lists):
+        for j, (o, v) in enumerate(l):
+            wt[src, j] = v
+            ft[src, j] = o
+    return wt, ft
+
+
 @register_operator(name='super_resolution')
 class SuperResolutionOperator(_FFTModelMixin, LinearOperator):
     """forward = antialiased bicubic 1/sf (Resizer); transpose / solvers model A as circular
@@ -292,11 +312,13 @@ class SuperResolutionOperator(_FFTModelMixin, LinearOperator):
         L.check(self.lib.kdip_op_set_psf(self._h, C.c_void_p(k.ctypes.data), k.shape[0], k.shape[1]))
         out_shape = tuple(int(s / scale_factor) for s in in_shape[-2:])
         self.out_shape = (1, 3, *out_shape)
-        self._tables = {}
+        self._tables, self._tables_T = {}, {}          # forward gather tables / their transposes (adjoint as a gather)
         for n_in in set(self.in_shape[-2:]):
             n_out = int(np.ceil(n_in / scale_factor))
             w, f = cubic_resize_tables(n_in, n_out, 1.0 / scale_factor)
             self._tables[n_in] = (torch.from_numpy(w).to(device), torch.from_numpy(f).to(device), w.shape[1], n_out)
+            wt, ft = transpose_resize_tables(w, f, n_in)
+            self._tables_T[n_in] = (torch.from_numpy(wt).to(device), torch.from_numpy(ft).to(device), wt.shape[1], n_out)
 
     def _resize(self, x, adjoint=False):
         """W axis first, then H (np.argsort of equal scales in the reference); adjoint reverses."""
@@ -312,10 +334,13 @@ class SuperResolutionOperator(_FFTModelMixin, LinearOperator):
             y = torch.empty(B, Cc, oH, oW, device=x.device)
             L.check(lib.kdip_resize_axis(st, L.ptr(t), L.ptr(wH), L.ptr(fH), tH, H, oH, oW, 0, planes, 0, L.ptr(y)))
             return y
+        # adjoint: the transposed tables on the forward (gather) kernel, axes in reverse order: [oH, oW] -> [H, oW] -> [H, W]
+        wHt, fHt, tHt, _ = self._tables_T[H]
+        wWt, fWt, tWt, _ = self._tables_T[W]
         t = torch.empty(B, Cc, H, oW, device=x.device)
-        L.check(lib.kdip_resize_axis(st, L.ptr(x), L.ptr(wH), L.ptr(fH), tH, H, oH, oW, 0, planes, 1, L.ptr(t)))
+        L.check(lib.kdip_resize_axis(st, L.ptr(x), L.ptr(wHt), L.ptr(fHt), tHt, oH, H, oW, 0, planes, 0, L.ptr(t)))
         g = torch.empty(B, Cc, H, W, device=x.device)
-        L.check(lib.kdip_resize_axis(st, L.ptr(t), L.ptr(wW), L.ptr(fW), tW, W, oW, H, 1, planes, 1, L.ptr(g)))
+        L.check(lib.kdip_resize_axis(st, L.ptr(t), L.ptr(wWt), L.ptr(fWt), tWt, oW, W, H, 1, planes, 0, L.ptr(g)))
         return g
 
     def forward(self, data, flatten=False, noiseless=False):
