@@ -94,3 +94,35 @@ def test_sampler_run_bitwise_reproducible(dt, opn, guid, cov, extra):
     assert torch.isfinite(a).all()
     nd = int((a != b).sum())
     assert nd == 0, (dt, opn, nd, float((a - b).abs().max()))
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16x3"])
+@pytest.mark.parametrize("cid", ["cfg3_imagenet_motion_typeI_analytic", "cfg4_gauss_v2_dwt_autoI"])
+def test_other_baseline_configs_bitwise_reproducible(dt, cid):
+    """BASELINE configs[3] (ImageNet-256 architecture: 16 attention blocks on the fp32 GEMM + softmax path, analytic covariance) and
+    configs[4] (V2 denoiser, DWT-Var covariance, auto Type-I: CG with the Haar DWT in the matvec below sigma 1): a 4-step Heun run
+    ending at sigma_min, batch 2, twice -> identical bits."""
+    import kdip_amd.unet as ku
+    import kdip_amd.condition as kc
+    import kdip_amd.external as ke
+    import kdip_amd.sampling as ks
+    from test_fullsize_gpu import _setup
+    from helpers import synthetic_recon_mse
+    B = 2
+    D = ku.GaussianDiffusionTables()
+    if cid.startswith("cfg3"):
+        m, sd, ocfg, hop, oop, meas, x0 = _setup("IMAGENET", "motion_blur", dt, B=B)
+        rm = {k: v.cuda() for k, v in synthetic_recon_mse().items()}
+        den = kc.ConditionOpenAIDenoiser(inner_model=m, diffusion=D, x0_cov_type="analytic", recon_mse=rm, operator=hop,
+                                         measurement=(meas[0].cuda(), meas[1].cuda()), guidance="I", device="cuda")
+    else:
+        m, sd, ocfg, hop, oop, meas, x0 = _setup("FFHQ", "gaussian_blur", dt, B=B, out_cov=True)
+        den = kc.ConditionOpenAIDenoiserV2(ke.OpenAIDenoiserV2(m, D, ortho_tf_type="dwt"), operator=hop, measurement=(meas[0].cuda(), meas[1].cuda()),
+                                           guidance="autoI", mle_sigma_thres=1.0, device="cuda", ortho_tf_type="dwt")
+    xT = torch.randn(B, 3, 256, 256, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)) * 80
+    sig = ks.get_sigmas_karras(4, 0.01, 80, rho=7.0, device="cuda")
+    a = ks.sample_heun(den, xT.clone(), sig, disable=True).clone()
+    b = ks.sample_heun(den, xT.clone(), sig, disable=True)
+    assert torch.isfinite(a).all()
+    nd = int((a != b).sum())
+    assert nd == 0, (dt, cid, nd, float((a - b).abs().max()))
