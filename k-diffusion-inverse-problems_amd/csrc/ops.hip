@@ -117,7 +117,10 @@ template <int LPB>
 __global__ __launch_bounds__(256) void blur_sep63_kernel(const float* __restrict__ x, const float* __restrict__ k,
                                                           int taps, int N, int axis, float* __restrict__ out) {
   constexpr int KT = 63, R = 8;
-  extern __shared__ float sm[];               // [LPB][N+1] lines
+  extern __shared__ float sm[];               // [LPB] lines of N samples, one pad word after every 8 (and one per line): in the row pass a wave's
+                                              // threads sit on consecutive 8-sample segments of ONE line -- a stride of 8 words is an 8-way bank
+                                              // conflict on every read (100 vs 61 us per 192-plane pass), a stride of 9 is none
+  const int LS = N + (N >> 3) + 1;
   const int tid = threadIdx.x;
   const long pbase = (long)blockIdx.y * N * N;
   const int line0 = blockIdx.x * LPB;
@@ -129,21 +132,22 @@ __global__ __launch_bounds__(256) void blur_sep63_kernel(const float* __restrict
     int l, i; long g;
     if (axis == 1) { l = e / N; i = e % N; g = pbase + (long)(line0 + l) * N + i; }
     else { i = e / LPB; l = e % LPB; g = pbase + (long)i * N + (line0 + l); }
-    sm[l * (N + 1) + i] = x[g];
+    sm[l * LS + i + (i >> 3)] = x[g];
   }
   __syncthreads();
   const int mask = N - 1, segs = N / R;
   for (int w = tid; w < LPB * segs; w += 256) {
     // axis 1: consecutive threads -> consecutive segments of a line; axis 0: consecutive threads -> consecutive lines
     const int l = axis == 1 ? w / segs : w % LPB, i0 = (axis == 1 ? w % segs : w / LPB) * R;
-    const float* ln = sm + l * (N + 1);
+    const float* ln = sm + l * LS;
     float acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = 0.f;
     // out[i0 + r] = sum_t k'[t] ln[(i0 + r - t + 31) & mask]; with j = r - t + 62: sample ln[(i0 + j - 31) & mask]
 #pragma unroll
     for (int j = 0; j < KT + R - 1; ++j) {
-      const float v = ln[(i0 + j - 31) & mask];
+      const int si = (i0 + j - 31) & mask;
+      const float v = ln[si + (si >> 3)];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const int t = r + (KT - 1) - j;       // compile-time after unrolling
@@ -163,11 +167,21 @@ int blur_sep_circ(hipStream_t st, const float* x, const float* k1d, int taps, in
   KDIP_REQUIRE((N & (N - 1)) == 0 && N >= 16, "blur: N=%d must be a power of two", N);
   constexpr int LPB = 16;
   if ((taps & 1) && taps <= 63 && N % 8 == 0) {
+#ifndef KDIP_BLUR_LPB_WIDE
+#define KDIP_BLUR_LPB_WIDE 32
+#endif
 #ifndef KDIP_BLUR_LPB
 #define KDIP_BLUR_LPB 8             // 8 lines per block = one 8-output segment per thread and 2 x the blocks: 20.7 -> 16.9 us per pass of 24 planes (16: 20.7, 4: 19.7)
 #endif
     constexpr int L63 = KDIP_BLUR_LPB;       // lines per block of the register-blocked kernel
-    hipLaunchKernelGGL(blur_sep63_kernel<L63>, dim3(N / L63, (unsigned)planes), dim3(256), sizeof(float) * L63 * (N + 1), st, x, k1d, taps, N,
+    // the column pass (axis 0) touches LPB consecutive floats of every row: 8 lines = 32-byte pieces of the 128-byte lines.  Once there
+    // are enough planes to fill the chip with 32-line blocks, take whole lines (KDIP_BLUR_LPB_WIDE); few planes keep the many small blocks
+    if (axis == 0 && N % KDIP_BLUR_LPB_WIDE == 0 && planes * (N / KDIP_BLUR_LPB_WIDE) >= 1024) {
+      constexpr int LW = KDIP_BLUR_LPB_WIDE;
+      hipLaunchKernelGGL(blur_sep63_kernel<LW>, dim3(N / LW, (unsigned)planes), dim3(256), sizeof(float) * LW * (N + N / 8 + 1), st, x, k1d, taps, N, axis, out);
+      KDIP_LAUNCH_CHECK(); return KDIP_OK;
+    }
+    hipLaunchKernelGGL(blur_sep63_kernel<L63>, dim3(N / L63, (unsigned)planes), dim3(256), sizeof(float) * L63 * (N + N / 8 + 1), st, x, k1d, taps, N,
                        axis, out);
     KDIP_LAUNCH_CHECK(); return KDIP_OK;
   }
@@ -235,9 +249,62 @@ __global__ void resize_axis_kernel(const float* __restrict__ x, const float* __r
     out[i] = s;
   }
 }
+// axis 1 (the contiguous axis) through LDS: a block stages ROWS whole input rows with coalesced 16-byte loads and keeps the (weight,
+// source index) tables in LDS; every thread then gathers its outputs from LDS.  (The direct form reads the tables and the samples with
+// per-lane addresses, three dependent loads per tap: 217 us per 192-plane pass against 21 us for the axis-0 pass of the same data.)
+template <int ROWS, int MAXT>
+__global__ __launch_bounds__(256) void resize_axis1_lds_kernel(const float* __restrict__ x, const float* __restrict__ w, const int* __restrict__ fov,
+                                                                int taps, int n_in, int n_out, long rows_total, float* __restrict__ out) {
+  extern __shared__ float rs_sm[];             // [ROWS] rows of n_in samples, one pad word after every 4 (neighbouring outputs read samples 1 / scale
+                                               // = 4 apart: a stride of 5 words spreads them over the banks) + one per row
+  const int LS = n_in + (n_in >> 2) + 1;
+  const int tid = threadIdx.x;
+  const long row0 = (long)blockIdx.x * ROWS;
+  const int nv = n_in / 4;                     // n_in % 4 == 0 (checked by the launcher)
+  for (int e = tid; e < ROWS * nv; e += 256) {
+    const int r = e / nv, v = e - r * nv;
+    if (row0 + r < rows_total) {
+      const float4 q = *(const float4*)(x + (row0 + r) * n_in + v * 4);
+      float* d = rs_sm + r * LS + v * 5;
+      d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
+    }
+  }
+  // thread -> (output column o, row group): the column's taps stay in registers for all its rows (padded to MAXT with weight 0)
+  const int ncol = n_out < 256 ? n_out : 256, ngrp = 256 / ncol;
+  const int oc = tid % ncol, grp = tid / ncol;
+  __syncthreads();
+  for (int o = oc; o < n_out; o += ncol) {
+    float wr[MAXT]; int fr[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      const bool live = t < taps;
+      wr[t] = live ? w[o * taps + t] : 0.f;
+      const int si = live ? fov[o * taps + t] : 0;
+      fr[t] = si + (si >> 2);
+    }
+    if (grp < ngrp) {
+      for (int r = grp; r < ROWS; r += ngrp) {
+        if (row0 + r >= rows_total) break;
+        const float* xr = rs_sm + r * LS;
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) acc += xr[fr[t]] * wr[t];
+        out[(row0 + r) * n_out + o] = acc;
+      }
+    }
+  }
+}
+
 int resize_axis(hipStream_t st, const float* x, const float* w, const int* fov, int taps, int n_in, int n_out, int other,
                 int axis, long planes, float* out) {
   ProfScope ps_(st, PC_OP_RESIZE, (double)planes * other * ((double)n_in + n_out) * sizeof(float), "resize", planes, n_in, n_out, axis);
+  constexpr int RROWS = 16, RMAXT = 16;
+  const size_t lds = sizeof(float) * (size_t)RROWS * (n_in + n_in / 4 + 1);
+  if (axis == 1 && n_in % 4 == 0 && ((uintptr_t)x % 16) == 0 && taps <= RMAXT && lds <= 60 * 1024) {
+    const long rows = planes * other;
+    hipLaunchKernelGGL((resize_axis1_lds_kernel<RROWS, RMAXT>), dim3((unsigned)((rows + RROWS - 1) / RROWS)), dim3(256), lds, st, x, w, fov, taps, n_in, n_out, rows, out);
+    KDIP_LAUNCH_CHECK(); return KDIP_OK;
+  }
   hipLaunchKernelGGL(resize_axis_kernel, dim3(pw_grid(planes * (long)n_out * other)), dim3(256), 0, st, x, w, fov, taps, n_in,
                      n_out, other, axis, planes, out);
   KDIP_LAUNCH_CHECK(); return KDIP_OK;
