@@ -128,11 +128,18 @@ __global__ __launch_bounds__(256) void blur_sep63_kernel(const float* __restrict
   const int shift = (KT - taps) / 2;          // taps odd <= 63: k'[t + shift] = k[t], half' = 31
 #pragma unroll
   for (int t = 0; t < KT; ++t) kr[t] = (t >= shift && t - shift < taps) ? k[t - shift] : 0.f;
-  for (int e = tid; e < LPB * N; e += 256) {
-    int l, i; long g;
-    if (axis == 1) { l = e / N; i = e % N; g = pbase + (long)(line0 + l) * N + i; }
-    else { i = e / LPB; l = e % LPB; g = pbase + (long)i * N + (line0 + l); }
-    sm[l * LS + i + (i >> 3)] = x[g];
+  if (axis == 1) {       // rows: 16-byte loads (N % 8 == 0, planes 16-byte aligned: checked by the launcher)
+    for (int e = tid; e < LPB * (N / 4); e += 256) {
+      const int l = e / (N / 4), i = (e % (N / 4)) * 4;
+      const float4 q = *(const float4*)(x + pbase + (long)(line0 + l) * N + i);
+      float* d = sm + l * LS + i + (i >> 3);       // (4 consecutive samples never straddle a pad: i % 4 == 0)
+      d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
+    }
+  } else {
+    for (int e = tid; e < LPB * N; e += 256) {
+      const int i = e / LPB, l = e % LPB;
+      sm[l * LS + i + (i >> 3)] = x[pbase + (long)i * N + (line0 + l)];
+    }
   }
   __syncthreads();
   const int mask = N - 1, segs = N / R;
@@ -143,21 +150,32 @@ __global__ __launch_bounds__(256) void blur_sep63_kernel(const float* __restrict
     float acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = 0.f;
-    // out[i0 + r] = sum_t k'[t] ln[(i0 + r - t + 31) & mask]; with j = r - t + 62: sample ln[(i0 + j - 31) & mask]
+    // out[i0 + r] = sum_t k'[t] ln[(i0 + r - t + 31) & mask]; with j = r - t + 62: sample ln[(i0 + j - 31) & mask].
+    // i0 is a multiple of 8: sample index = (b + k) & mask with b = (i0 - 32) & mask (a multiple of 8) and k = j + 1, so the padded LDS
+    // index is 9 * (((b >> 3) + (k >> 3)) & (N / 8 - 1)) + (k & 7): one wrap per group of 8 samples instead of three VALU per sample
+    const int b8 = ((i0 - 32) & mask) >> 3, m8 = (N >> 3) - 1;
 #pragma unroll
-    for (int j = 0; j < KT + R - 1; ++j) {
-      const int si = (i0 + j - 31) & mask;
-      const float v = ln[si + (si >> 3)];
+    for (int kq = 0; kq <= (KT + R - 1) / 8; ++kq) {
+      const float* grp = ln + ((b8 + kq) & m8) * 9;
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int t = r + (KT - 1) - j;       // compile-time after unrolling
-        if (t >= 0 && t < KT) acc[r] += kr[t] * v;
+      for (int k7 = 0; k7 < 8; ++k7) {
+        const int j = kq * 8 + k7 - 1;        // compile-time after unrolling
+        if (j < 0 || j >= KT + R - 1) continue;
+        const float v = grp[k7];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int t = r + (KT - 1) - j;
+          if (t >= 0 && t < KT) acc[r] += kr[t] * v;
+        }
       }
     }
+    if (axis == 1) {     // 8 consecutive outputs of a row: two 16-byte stores
+      float4* o4 = (float4*)(out + pbase + (long)(line0 + l) * N + i0);
+      o4[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      o4[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    } else {
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const long g = axis == 1 ? pbase + (long)(line0 + l) * N + (i0 + r) : pbase + (long)(i0 + r) * N + (line0 + l);
-      out[g] = acc[r];
+      for (int r = 0; r < R; ++r) out[pbase + (long)(i0 + r) * N + (line0 + l)] = acc[r];
     }
   }
 }
@@ -166,7 +184,7 @@ int blur_sep_circ(hipStream_t st, const float* x, const float* k1d, int taps, in
   ProfScope ps_(st, PC_OP_BLUR, (double)planes * N * N * sizeof(float) * 2, "blur_sep", planes, N, taps, axis);
   KDIP_REQUIRE((N & (N - 1)) == 0 && N >= 16, "blur: N=%d must be a power of two", N);
   constexpr int LPB = 16;
-  if ((taps & 1) && taps <= 63 && N % 8 == 0) {
+  if ((taps & 1) && taps <= 63 && N % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0) {
 #ifndef KDIP_BLUR_LPB_WIDE
 #define KDIP_BLUR_LPB_WIDE 32
 #endif
@@ -176,7 +194,8 @@ int blur_sep_circ(hipStream_t st, const float* x, const float* k1d, int taps, in
     constexpr int L63 = KDIP_BLUR_LPB;       // lines per block of the register-blocked kernel
     // the column pass (axis 0) touches LPB consecutive floats of every row: 8 lines = 32-byte pieces of the 128-byte lines.  Once there
     // are enough planes to fill the chip with 32-line blocks, take whole lines (KDIP_BLUR_LPB_WIDE); few planes keep the many small blocks
-    if (axis == 0 && N % KDIP_BLUR_LPB_WIDE == 0 && planes * (N / KDIP_BLUR_LPB_WIDE) >= 1024) {
+    // (both passes: a block also loads the 63 taps once, amortised over 4 x the work)
+    if (N % KDIP_BLUR_LPB_WIDE == 0 && planes * (N / KDIP_BLUR_LPB_WIDE) >= 1024) {
       constexpr int LW = KDIP_BLUR_LPB_WIDE;
       hipLaunchKernelGGL(blur_sep63_kernel<LW>, dim3(N / LW, (unsigned)planes), dim3(256), sizeof(float) * LW * (N + N / 8 + 1), st, x, k1d, taps, N, axis, out);
       KDIP_LAUNCH_CHECK(); return KDIP_OK;
