@@ -262,6 +262,12 @@ template <typename T, int NTAPS, int TILE> constexpr int kc_of() { return (std::
 #ifndef KDIP_X3_TF_APF
 #define KDIP_X3_TF_APF 1     // GroupNorm-staging instantiation: 1 = A-fragment prefetch + one weight stage in flight; 0 = no prefetch + two stages
 #endif
+#ifndef KDIP_EPI32_SB
+#define KDIP_EPI32_SB 4      // fp32-storage epilogue, backward-statistics sweep: pixel rows requested per batch (the accumulators are dead there)
+#endif
+#ifndef KDIP_X3_TF_BD2
+#define KDIP_X3_TF_BD2 0     // GroupNorm-staging instantiation: 1 = A-fragment prefetch AND two weight stages in flight (fits since the 16-channel stages)
+#endif
 #ifndef KDIP_X3_TW
 #define KDIP_X3_TW 16        // patch width of the split-precision instantiations
 #endif
@@ -617,7 +623,7 @@ __device__ __forceinline__ void epilogue_f32_fast(const ConvParams& p, f32x16 (&
       ca[0] = c0.x; ca[1] = c0.z; ca[2] = c1.x; ca[3] = c1.z; cb[0] = c0.y; cb[1] = c0.w; cb[2] = c1.y; cb[3] = c1.w;
       mrv = *(const float2*)(p.st_mr + ((long)img0 * 32 + nl / cpg) * 2);
     }
-    constexpr int SB = (MT * NPASS) % 4 == 0 ? 4 : 2;
+    constexpr int SB = (MT * NPASS) % KDIP_EPI32_SB == 0 ? KDIP_EPI32_SB : ((MT * NPASS) % 4 == 0 ? 4 : 2);
 #pragma unroll 1
     for (int q0 = 0; q0 < MT * NPASS; q0 += SB) {
       float4 rd[SB], rx[SB];
@@ -911,7 +917,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
   };
   // the staging-transform instantiation trades the A-fragment prefetch (KDIP_X3_TF_APF 0: 48 registers) for the second weight stage
   constexpr bool APF = KDIP_A_PREFETCH && !(X3 && TFM && !KDIP_X3_TF_APF);
-  constexpr int BD = X3 ? ((NTAPS == 9 && (!TFM || !KDIP_X3_TF_APF)) ? KDIP_X3_B_DEPTH : 1) : (MT * NT <= 2 && sizeof(T) == 2 && NTAPS == 9) ? KDIP_B_DEPTH_SMALL : KDIP_B_DEPTH;   // stages ahead
+  constexpr int BD = X3 ? ((NTAPS == 9 && (!TFM || !KDIP_X3_TF_APF || KDIP_X3_TF_BD2)) ? KDIP_X3_B_DEPTH : 1) : (MT * NT <= 2 && sizeof(T) == 2 && NTAPS == 9) ? KDIP_B_DEPTH_SMALL : KDIP_B_DEPTH;   // stages ahead
   uint4 bq[BD + 1][KS][NT][NPB];
 
   // prologue: the first two B stages are requested together with the first patch, ahead of the LDS write + barrier
