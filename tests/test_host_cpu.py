@@ -111,6 +111,25 @@ def test_resize_tables_match_oracle():
         assert np.array_equal(w, wo.astype(np.float32))
 
 
+def test_transposed_resize_tables_are_the_adjoint():
+    """The Resizer adjoint runs as a gather on transposed tables (kdip_amd.measurements.transpose_resize_tables): as dense matrices,
+    transposed table == (forward table)^T exactly -- mirrored borders (an input index hit twice by one output) included."""
+    from kdip_amd.measurements import cubic_resize_tables, transpose_resize_tables
+    for n_in, n_out, scale in ((256, 64, 0.25), (64, 16, 0.25), (96, 32, 1.0 / 3), (64, 32, 0.5)):
+        w, f = cubic_resize_tables(n_in, n_out, scale)
+        A = np.zeros((n_out, n_in), np.float64)
+        for o in range(n_out):
+            for t in range(w.shape[1]):
+                A[o, f[o, t]] += w[o, t]
+        wt, ft = transpose_resize_tables(w, f, n_in)
+        At = np.zeros((n_in, n_out), np.float64)
+        for s_ in range(n_in):
+            for j in range(wt.shape[1]):
+                At[s_, ft[s_, j]] += wt[s_, j]
+        assert wt.dtype == np.float32 and ft.dtype == np.int32 and ft.min() >= 0 and ft.max() < n_out
+        assert np.array_equal(At, A.T)
+
+
 def test_registries():
     import kdip_amd.measurements as km
     import kdip_amd.condition as kc
