@@ -397,8 +397,12 @@ __device__ inline void put_sub(float* o, int N, int size, int bi, int bj, const 
 #pragma unroll
     for (int j = 0; j < S; ++j) {
       int r = bi * S + i, c = bj * S + j;
-      o[(long)r * N + size + c] = da[i][j];
-      o[(long)(size + r) * N + c] = ad[i][j];
+      // pywt.coeffs_to_array places a detail block by its dwtn KEY: first letter = axis -2 (rows), second = axis -1 (columns); 'a' -> the
+      // leading half of that axis, 'd' -> the trailing half.  So 'ad' (approximation down the rows, detail along the columns: pywt's cV) sits
+      // TOP-RIGHT and 'da' (pywt's cH) BOTTOM-LEFT -- pinned against PyWavelets 1.1.1 (tests/golden/thirdparty_pins.npz).  Rounds 1 - 4 had
+      // the two blocks exchanged (restated from the documentation's cH / cV figure without the package at hand).
+      o[(long)r * N + size + c] = ad[i][j];
+      o[(long)(size + r) * N + c] = da[i][j];
       o[(long)(size + r) * N + size + c] = dd[i][j];
     }
 }
@@ -410,8 +414,8 @@ __device__ inline void get_sub(const float* o, int N, int size, int bi, int bj, 
 #pragma unroll
     for (int j = 0; j < S; ++j) {
       int r = bi * S + i, c = bj * S + j;
-      da[i][j] = o[(long)r * N + size + c];
-      ad[i][j] = o[(long)(size + r) * N + c];
+      ad[i][j] = o[(long)r * N + size + c];          // top-right: 'ad' (see put_sub)
+      da[i][j] = o[(long)(size + r) * N + c];          // bottom-left: 'da'
       dd[i][j] = o[(long)(size + r) * N + size + c];
     }
 }

@@ -1,9 +1,9 @@
 """Evaluation metrics of the caller harness -- `compute_metrics` / `calculate_average_metric`
 (sample_condition_openai.py:41-68).
 
-PSNR and SSIM are restated from their published definitions (skimage.metrics is not importable in
-the build container, so SSIM parity is *unpinned*: tests check it against an independent
-scipy.ndimage restatement of the same algorithm).  LPIPS (kdip_amd.lpips.LPIPS, the VGG forward on the
+PSNR and SSIM are restated from their published definitions and PINNED (round 5) against scikit-image 0.18.3 itself
+(`skimage.metrics.peak_signal_noise_ratio` / `structural_similarity`, the package found in this image's conda interpreter:
+oracle/make_golden_thirdparty.py -> tests/golden/thirdparty_pins.npz; tests/test_thirdparty_pins.py: PSNR to 1e-6 dB, SSIM to 1e-10).  LPIPS (kdip_amd.lpips.LPIPS, the VGG forward on the
 HIP conv kernels) is reported when a loaded `loss_fn_vgg` is passed, as in the reference; its pretrained
 weights are not obtainable offline, so without a checkpoint the key is omitted rather than faked.
 """

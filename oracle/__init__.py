@@ -19,9 +19,10 @@ VJP exactly as the reference does (condition/condition.py:172).
 
 Parity pinning: the restatement is validated against the real reference,
 imported in the build container by `oracle/make_golden.py` (which also writes
-the committed fixtures under tests/golden/).  Two third-party boundaries
-cannot be executed here and are **parity unpinned** (SURVEY.md section 8c):
-PyWavelets (Haar level-3 `wavedec2` + `coeffs_to_array` layout, restated from
-its documented definition) and GPyTorch (`autoI`, restated as Type-I with a
-CG solve).
+the committed fixtures under tests/golden/).  Third-party boundaries
+(SURVEY.md section 8c): PyWavelets, scikit-image and the legacy-`tol` SciPy `cg`
+are pinned against the real packages (found in /opt/conda/bin/python3.9:
+`oracle/make_golden_thirdparty.py` -> tests/golden/thirdparty_pins.npz);
+GPyTorch (`autoI`, restated as Type-I with a CG solve) and `lpips` cannot be
+executed here and stay **parity unpinned**.
 """

@@ -38,7 +38,14 @@ def install_shims():
     tv.utils = sys.modules["torchvision.utils"]
     tv.transforms = sys.modules["torchvision.transforms"]
     tv.datasets = _stub("torchvision.datasets")
-    _stub("pywt")
+    # PyWavelets: the real package lives in this image's second interpreter (/opt/conda/bin/python3.9); its four functions the
+    # reference calls (condition/utils.py:116-132) are forwarded there (oracle/pywt_bridge.py).  Without that interpreter: empty stub.
+    from . import pywt_bridge
+    if pywt_bridge.available():
+        _stub("pywt", wavedec2=pywt_bridge.wavedec2, coeffs_to_array=pywt_bridge.coeffs_to_array,
+              array_to_coeffs=pywt_bridge.array_to_coeffs, waverec2=pywt_bridge.waverec2, __kdip_bridge__=True)
+    else:
+        _stub("pywt")
     gp = _stub("gpytorch", LinearOperator=object)
     _stub("gpytorch.distributions", MultivariateNormal=object)
     _stub("hdf5storage", loadmat=scipy.io.loadmat)

@@ -2,15 +2,14 @@
 
 TEST INFRASTRUCTURE (see oracle/__init__.py).
 
-PARITY UNPINNED for 'dwt': PyWavelets is not installable here, so the Haar
-level-3 `wavedec2` + `coeffs_to_array` pair (condition/utils.py:116-132) is
-restated from PyWavelets' documented definition (unpinned version, absent from
-environment.yml):  dec_lo = [1/sqrt2, 1/sqrt2], dec_hi = [-1/sqrt2, 1/sqrt2]
-=> cA[k] = (x[2k]+x[2k+1])/sqrt2, cD[k] = (x[2k]-x[2k+1])/sqrt2; 2-D keys are
-'<axis -2><axis -1>' with a=approx, d=detail; `coeffs_to_array` puts cA_L top
-left and per level 'da' (cH) top-right, 'ad' (cV) bottom-left, 'dd' (cD)
-bottom-right.  Self-checks available and tested: orthonormality, perfect
-reconstruction.
+'dwt' is PINNED (round 5) against PyWavelets 1.1.1 -- the real package, found in this image's conda interpreter
+(/opt/conda/bin/python3.9; oracle/make_golden_thirdparty.py -> tests/golden/thirdparty_pins.npz: forward, inverse, fp32 /
+fp64, three sizes, sub-band impulses).  Haar level-3 `wavedec2` + `coeffs_to_array` (condition/utils.py:116-132):
+dec_lo = [1/sqrt2, 1/sqrt2], dec_hi = [-1/sqrt2, 1/sqrt2] => cA[k] = (x[2k]+x[2k+1])/sqrt2, cD[k] = (x[2k]-x[2k+1])/sqrt2;
+2-D keys are '<axis -2><axis -1>' with a=approx, d=detail; `coeffs_to_array` places a block by its key ('a' = leading half of
+that axis, 'd' = trailing half): cA_L top-left and per level 'ad' (pywt's cV: approx down the rows, detail along the columns)
+TOP-RIGHT, 'da' (cH) BOTTOM-LEFT, 'dd' (cD) bottom-right.  Rounds 1-4 restated the placement from the documentation's cH / cV
+figure without the package and had 'ad' and 'da' exchanged; the pin found it.
 
 'dct' follows scipy.fft.dctn(norm='ortho') over *all* axes of the batch-1
 tensor (condition/utils.py:91-103); the length-1 batch axis is an identity, so
@@ -58,8 +57,8 @@ def dwt_haar(x, level=3):
     for _ in range(level):
         aa, da, ad, dd = _haar_step(cur)
         h, w = aa.shape[-2], aa.shape[-1]
-        out[..., :h, w:2 * w] = da
-        out[..., h:2 * h, :w] = ad
+        out[..., :h, w:2 * w] = ad          # top-right: key 'ad'
+        out[..., h:2 * h, :w] = da          # bottom-left: key 'da'
         out[..., h:2 * h, w:2 * w] = dd
         cur = aa
     out[..., :cur.shape[-2], :cur.shape[-1]] = cur
@@ -70,8 +69,8 @@ def idwt_haar(c, level=3):
     h, w = c.shape[-2] >> level, c.shape[-1] >> level
     cur = c[..., :h, :w]
     for _ in range(level):
-        da = c[..., :h, w:2 * w]
-        ad = c[..., h:2 * h, :w]
+        ad = c[..., :h, w:2 * w]
+        da = c[..., h:2 * h, :w]
         dd = c[..., h:2 * h, w:2 * w]
         cur = _haar_istep(cur, da, ad, dd)
         h, w = h * 2, w * 2

@@ -189,8 +189,8 @@ FULLSIZE = [
 def test_baseline_configs_fullsize_vs_oracle(cid, opn, guid, cov, extra, ortho, sig_lo):
     """One high-sigma and one low-sigma guided call of BASELINE configs[0] / [2] / [4] at 256 x 256 (FFHQ architecture, batch 2)
     against the CPU oracle on the same inputs: f32 and bf16x3 within 2e-3 max-abs (the f32-mode bound of the guided-call goldens),
-    bf16 as PSNR(hip, oracle), printed and bounded.  configs[4] rides on the DWT layout restated from pywt's documentation
-    (parity unpinned at that third-party boundary, oracle/transforms.py)."""
+    bf16 as PSNR(hip, oracle), printed and bounded.  configs[4] rides on the Haar-3 DWT layout of pywt
+    (pinned against PyWavelets 1.1.1 since round 5: tests/test_thirdparty_pins.py)."""
     import kdip_amd.unet as ku
     import kdip_amd.condition as kc
     import kdip_amd.external as ke

@@ -99,7 +99,7 @@ def test_transforms(gold):
     x = T(g["x"])
     assert float((otf.dct_ortho(x) - T(g["dct"])).abs().max()) < 5e-6
     assert float((otf.idct_ortho(T(g["dct"])) - x).abs().max()) < 5e-6
-    # Haar (parity unpinned; definition-level self-checks)
+    # Haar: definition-level self-checks (the pin against PyWavelets itself is tests/test_thirdparty_pins.py)
     w = otf.dwt_haar(x)
     assert float((otf.idwt_haar(w) - x).abs().max()) < 1e-5
     assert abs(float(w.norm() / x.norm()) - 1) < 1e-6
@@ -107,10 +107,11 @@ def test_transforms(gold):
     wc = otf.dwt_haar(c)
     assert abs(float(wc[0, 0, 0, 0]) - 16.0) < 1e-5          # cA3 = 2 * (sqrt2)^6
     assert float(wc[0, 0, 8:, :].abs().max()) == 0 and float(wc[0, 0, :8, 8:].abs().max()) == 0
-    # a vertical edge between columns 0|1 excites 'ad' (detail along W) = bottom-left block of level 1
+    # a vertical edge between columns 0|1 excites 'ad' (approximation down the rows, detail along W) = the TOP-RIGHT block of level 1
+    # (pywt.coeffs_to_array places blocks by key: first letter = rows, second = columns, 'd' = trailing half)
     e = torch.zeros(1, 1, 64, 64); e[..., :, 0] = 1
     we = otf.dwt_haar(e)
-    assert float(we[0, 0, 32:, :32].abs().max()) > 0 and float(we[0, 0, :32, 32:].abs().max()) == 0
+    assert float(we[0, 0, :32, 32:].abs().max()) > 0 and float(we[0, 0, 32:, :32].abs().max()) == 0
 
 
 def _ops_and_meas(gold, name):
@@ -155,6 +156,25 @@ def test_guided_calls_v2(gold):
                 m = ocond.GuidedDenoiser(sd, cfg, op, meas, guidance, mle_sigma_thres=1.0, v2=True)
                 hat = m(x, torch.tensor([sigma_v]))
                 assert float((hat - T(g[f"{name}|{guidance}|v2|{sigma_v}"])).abs().max()) < 2e-4
+
+
+def test_guided_calls_v2_transform_bases(gold):
+    """Reference captures of the V2 denoiser with the DWT-Var / DCT-Var covariance (BASELINE configs[4]'s machinery: OrthoTransform inside
+    the mat-solvers, condition/condition.py:317-439; condition/utils.py:88-163) -- produced by the REFERENCE with the real PyWavelets
+    (oracle/make_golden_v2dwt.py, oracle/pywt_bridge.py): guidance I / II x sigma 1.5 (scalar variance), 0.5 and 0.12 (learned
+    theta-variance, CG with the transform in the matvec)."""
+    g = gold("guided_calls_v2_ot")
+    cfg = ounet.UNetConfig(**ounet.TINY)
+    sd = ounet.init_state_dict(cfg, seed=0, out_cov=True)
+    for basis in ("dwt", "dct"):
+        for name in ("gaussian_blur", "inpainting", "super_resolution"):
+            op, meas, x0 = _ops_and_meas(gold, name)
+            for guidance in ("I", "II"):
+                for sigma_v in (1.5, 0.5, 0.12):
+                    x = x0 + sigma_v * torch.randn(1, 3, 64, 64, generator=torch.Generator().manual_seed(11))
+                    m = ocond.GuidedDenoiser(sd, cfg, op, meas, guidance, mle_sigma_thres=1.0, v2=True, ortho_tf_type=basis)
+                    hat = m(x, torch.tensor([sigma_v]))
+                    assert float((hat - T(g[f"{name}|{guidance}|v2|{basis}|{sigma_v}"])).abs().max()) < 2e-4, (basis, name, guidance, sigma_v)
 
 
 def test_sampler_trajectories(gold):

@@ -235,9 +235,37 @@ def test_guided_calls_v2_golden(gold, tiny):
                     assert float((hat - ref).abs().max()) < 2e-3, (dt, name, guidance, sigma_v)
 
 
+def test_guided_calls_v2_transform_bases_golden(gold, tiny):
+    """HIP path vs the REFERENCE's own captures of the V2 denoiser with a DWT / DCT covariance basis (BASELINE configs[4]'s machinery;
+    fixtures written by the reference with the real PyWavelets 1.1.1: oracle/make_golden_v2dwt.py): Type-I and Type-II, scalar variance
+    (sigma 1.5) and learned theta-variance with on-device CG in the transform basis (sigma 0.5, 0.12), f32 and bf16x3."""
+    import kdip_amd.condition as kc
+    import kdip_amd.external as ke
+    models, D, sd, cfg = tiny
+    g = gold("guided_calls_v2_ot")
+    worst = {"f32": 0.0, "bf16x3": 0.0}
+    for basis in ("dwt", "dct"):
+        for name in ("gaussian_blur", "inpainting", "super_resolution"):
+            hop, oop, (y, yf), x0 = make_ops(name, gold)
+            meas = (y.cuda(), yf.cuda())
+            for guidance in ("I", "II"):
+                for sigma_v in (1.5, 0.5, 0.12):
+                    x = (x0 + sigma_v * torch.randn(1, 3, 64, 64, generator=torch.Generator().manual_seed(11))).cuda()
+                    ref = T(g[f"{name}|{guidance}|v2|{basis}|{sigma_v}"])
+                    for dt in ("f32", "bf16x3"):
+                        den = ke.OpenAIDenoiserV2(models[dt], D, ortho_tf_type=basis)
+                        m = kc.ConditionOpenAIDenoiserV2(den, operator=hop, measurement=meas, guidance=guidance, mle_sigma_thres=1.0,
+                                                         device="cuda", ortho_tf_type=basis).eval()
+                        hat = m(x, torch.tensor([sigma_v], device="cuda")).cpu()
+                        e = float((hat - ref).abs().max())
+                        worst[dt] = max(worst[dt], e)
+                        assert e < 2e-3, (dt, basis, name, guidance, sigma_v, e)
+    print(f"\nV2 + DWT / DCT bases vs reference captures: worst max-abs f32 {worst['f32']:.2e}, bf16x3 {worst['bf16x3']:.2e}")
+
+
 def test_v2_dwt_autoI_vs_oracle(gold, tiny):
     """config-5 shape of the path: v2 denoiser, DWT basis, autoI (= Type-I gradient), low sigma -> CG
-    with DWT in the matvec.  Parity unpinned at pywt/gpytorch; checked against the oracle restatement."""
+    with DWT in the matvec.  pywt's transform is pinned (tests/test_thirdparty_pins.py), GPyTorch's likelihood is not; checked against the oracle restatement."""
     import kdip_amd.condition as kc
     import kdip_amd.external as ke
     from oracle import condition as ocond
