@@ -217,11 +217,10 @@ int kdip_lpips_layer(void* stream, const float* f0_dev, const float* f1_dev, con
 /* ------------------------------------------------------------- CU-masked streams
  * A HIP stream restricted to the compute units whose bits are set in mask_words (hipExtStreamCreateWithCUMask).  Two part-batches
  * of a GPU's batch on two such streams with disjoint masks share the chip by SPACE: one stream's persistent conv launches (every
- * CU's LDS full) no longer lock the other stream's small-map kernels out.  kdip_debug_cu_census reports where blocks of a stream
- * run (out_host[2b] = HW_ID, out_host[2b+1] = XCC_ID of block b). */
+ * CU's LDS full) no longer lock the other stream's small-map kernels out.  (include/kdip_internal.h: kdip_debug_cu_census reports where the
+ * blocks of such a stream run.) */
 int kdip_stream_create_cu_mask(int device, const unsigned* mask_words, int nwords, void** stream_out);
 int kdip_stream_destroy(void* stream);
-int kdip_debug_cu_census(void* stream, int blocks, unsigned* out_host);
 
 /* ------------------------------------------------------------- one guided call (kdip_guided_step)
  * ConditionOpenAIDenoiser._type_I_guidance_impl (condition/condition.py:167-174) with uncond_pred (:231-274) in ONE entry point:
@@ -240,39 +239,6 @@ int kdip_guided_ws_layout(int B, int S, long* offsets_host, int count);
 int kdip_guided_call_v1(kdip_unet* u, kdip_op* op, void* stream, const float* x_dev, const float* t_dev, const float* y_dev, int B,
                         const float* tables7_host, float sigma, float var_scalar, int tensor_var, float* ws_dev, float* hat_dev,
                         int* cg_iters_host, int* cg_info_host);
-
-/* ------------------------------------------------------------------ low-level test hooks
- * (exercised by tests/ to localise kernel bugs; NHWC tensors of the UNet storage dtype) */
-int kdip_test_conv(void* stream, int dtype, int ntaps, const float* x_nchw_dev, int B, int Cin, int H, int W,
-                   const float* w_host, const float* bias_host, int Cout, int transpose_flip, float* y_nchw_dev,
-                   int storage_out /* 0: fp32 NHWC epilogue (output heads); 1: storage-dtype epilogue (UNet-internal) */);
-/* Test hook of the fused attention forward + VJP (replaces QKVAttentionLegacy.forward, guided_diffusion/unet.py:339-356, and its
- * autograd backward): device fp32 qkv [B][T][3C] (C = 64 * heads, head h at channels 192 h + q | k | v), dO [B][T][C]; inputs are
- * rounded to bf16; outputs o [B][T][C], dqkv [B][T][3C] as fp32.  T must be a multiple of 64. */
-int kdip_test_attention(void* stream, const float* qkv_dev, const float* dO_dev, int B, int T, int heads, float* o_dev, float* dqkv_dev);
-
-/* Second-generation bf16 3x3 conv (csrc/conv3.hip) with its fused GroupNorm staging transforms and epilogue statistics.
- * Tensor arguments are device fp32 NCHW; tf 1: tf_coef [B][Cin][2] = (a, b); tf 2: x = dy, x2 = GroupNorm input,
- * tf_coef [B][Cin][4] = (a, b, k0, k1); st_mode 1 / 2: sums_dev [B][32][2] (fp64) receives the GroupNorm forward / backward
- * sums of the output (mode 2: stx = GroupNorm input of the output, st_coef [B][Cout][2], st_mr [B][32][2]).
- * reps > 1: mean HIP-event microseconds per launch in *avg_us_host. */
-int kdip_test_conv3(void* stream, const float* x_nchw_dev, const float* x2_nchw_dev, int B, int Cin, int H, int W,
-                    const float* w_host, const float* bias_host, int Cout, int transpose_flip, int tf, const float* tf_coef_dev,
-                    const float* res_nchw_dev, int in_ups, int res_ups, int st_mode, const float* stx_nchw_dev,
-                    const float* st_coef_dev, const float* st_mr_dev, float* y_nchw_dev, double* sums_dev, int reps,
-                    float* avg_us_host);
-int kdip_test_groupnorm(void* stream, int dtype, const float* x_nchw_dev, int B, int C, int H, int W,
-                        const float* gamma_host, const float* beta_host, const float* film_host, int silu,
-                        float* y_nchw_dev, const float* dy_nchw_dev, float* dx_nchw_dev);
-/* Diagnostic (libraries built with -DKDIP_TIMING=1 only; KDIP_ERR_UNSUPPORTED otherwise): every later 3x3 conv launch
- * matching (H, real Cin, Cout, fused-statistics mode) writes per-block phase timestamps (100 MHz ticks: start, first patch
- * staged, K loop done, end, + 3 epilogue sub-phases) to dev_buf[grid][8] (uint64).  dev_buf = NULL switches it off.  tools/conv_phases.py. */
-int kdip_debug_conv_timing(void* dev_buf, int H, int cin, int cout, int st_mode);
-/* Same for csrc/conv3.hip (-DC3_TIMING=1): dev_buf[grid][8] = start, first patch staged, K loop done, end (100 MHz ticks), XCC id. */
-int kdip_debug_conv3_timing(void* dev_buf);
-/* Test / A-B aid: 1 (default) = the large-map bf16 convs compute their GroupNorm staging coefficients from the statistics themselves
- * (no gn_coef / gn_merge_stats / gn_bwd_coef launches between two convs); 0 = separate coefficient kernels.  Results are bit-identical. */
-int kdip_debug_gn_fold(int on);
 
 #ifdef __cplusplus
 }

@@ -26,7 +26,7 @@ def build(force=False, verbose=True, extra_flags=(), out=None, tag=""):
     out = out or OUT
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    headers.append(os.path.join(HERE, "..", "include", "kdip.h"))
+    headers += [os.path.join(HERE, "..", "include", h) for h in ("kdip.h", "kdip_internal.h")]
     jobs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)

@@ -2,7 +2,7 @@
 #include <stdlib.h>
 #include <vector>
 #include <mutex>
-#include "../../include/kdip.h"
+#include "../../include/kdip_internal.h"
 #include "kernels.h"
 #include "fftops.h"
 #include "opctx.h"

@@ -227,9 +227,7 @@ template <typename T, int NTAPS, int TILE> constexpr int kc_of() { return (std::
 #ifndef KDIP_SPLITK_MINCH
 #define KDIP_SPLITK_MINCH 2    // at least this many K chunks per split
 #endif
-#ifndef KDIP_SPLITK_MAX
-#define KDIP_SPLITK_MAX 16
-#endif
+static_assert(KDIP_SPLITK_MAX >= 1 && KDIP_SPLITK_MAX <= 64, "KDIP_SPLITK_MAX (kernels.h) out of range");
 #ifndef KDIP_SPLITK_FILL
 #define KDIP_SPLITK_FILL 512   // split K until a launch has about this many blocks (2 per CU)
 #endif
@@ -1512,8 +1510,11 @@ static uint16_t f32_to_f16_bits(float f) {
   return (uint16_t)(sign | (e << 10) | m);
 }
 
-std::atomic<long> g_x3_weight_sat{0};      // split-precision weights outside the fp16 window, counted by pack_conv_weight (read by UNet::finalize)
-long x3_weight_saturations() { return g_x3_weight_sat.load(); }
+// split-precision weights outside the fp16 window, counted by pack_conv_weight.  Per host THREAD: UNet::finalize packs a handle's weights on the
+// calling thread and takes the difference across its own packing, so finalizes running concurrently on other threads (multi-stream bench parts,
+// one handle per rank thread) cannot set bit 1 of kdip_unet_x3_saturated on a handle whose own weights were in range.
+static thread_local long t_x3_weight_sat = 0;
+long x3_weight_saturations() { return t_x3_weight_sat; }
 
 void pack_conv_weight(DType dt, const float* w, int Cout, int Cin, int ntaps, int transpose_flip, int Cin_pad_out,
                       void* out) {
@@ -1535,7 +1536,7 @@ void pack_conv_weight(DType dt, const float* w, int Cout, int Cin, int ntaps, in
           for (int lane = 0; lane < 64; ++lane)
             for (int e = 0; e < 8; ++e) {
               const float v = W(nt * 32 + (lane & 31), ks * 16 + (lane >> 5) * 8 + e, tap) * X3_S;     // exact power-of-two scaling
-              if (KDIP_X3_MIXED && fabsf(v) > 65504.f) g_x3_weight_sat.fetch_add(1);                        // the f16 re-encoded head saturates (|w| > 255.9)
+              if (KDIP_X3_MIXED && fabsf(v) > 65504.f) ++t_x3_weight_sat;                              // the f16 re-encoded head saturates (|w| > 255.9)
               const bf16_t hi = f32_to_bf16(v);
               o[idx + lane * 8 + e] = hi;
               const float lo = v - bf16_to_f32(hi);

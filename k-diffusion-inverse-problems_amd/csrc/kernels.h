@@ -6,6 +6,9 @@
 namespace kdip {
 
 // ---- conv.hip ---------------------------------------------------------------------------
+#ifndef KDIP_SPLITK_MAX
+#define KDIP_SPLITK_MAX 16      // most K splits of an under-filled 3x3 launch = slabs of the deterministic split-K workspace (unet.hip sizes it with this)
+#endif
 // Optional GroupNorm statistics fused into the conv epilogue (see ConvParams::st_mode).
 struct ConvStats {
   int mode = 0, silu = 0;
@@ -36,7 +39,7 @@ int conv_forward(hipStream_t st, DType dt, int ntaps, const void* x, long ldx, i
 // sk_ws: optional fp32 split-K workspace of sk_ws_floats floats, all zero on entry and on return; when given, under-filled
 // launches (small-spatial layers) split their K range over blockIdx.y and reduce through it
 size_t packed_weight_bytes(DType dt, int ntaps, int Cin_pad, int Cout);
-long x3_weight_saturations();       // running count of DT_F32X3 weights packed so far whose scaled value left the fp16 window (|w| > 255.9)
+long x3_weight_saturations();       // running count (of the calling host thread) of DT_F32X3 weights packed so far whose scaled value left the fp16 window (|w| > 255.9)
 int conv_debug_timing(void* buf, int H, int cin, int cout, int st_mode);   // -DKDIP_TIMING=1 diagnostic builds only
 void pack_conv_weight(DType dt, const float* w, int Cout, int Cin, int ntaps, int transpose_flip, int Cin_pad_out,
                       void* out);

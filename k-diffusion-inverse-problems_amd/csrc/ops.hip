@@ -195,16 +195,21 @@ int blur_sep_circ(hipStream_t st, const float* x, const float* k1d, int taps, in
     // the column pass (axis 0) touches LPB consecutive floats of every row: 8 lines = 32-byte pieces of the 128-byte lines.  Once there
     // are enough planes to fill the chip with 32-line blocks, take whole lines (KDIP_BLUR_LPB_WIDE); few planes keep the many small blocks
     // (both passes: a block also loads the 63 taps once, amortised over 4 x the work)
-    if (N % KDIP_BLUR_LPB_WIDE == 0 && planes * (N / KDIP_BLUR_LPB_WIDE) >= 1024) {
+    // (dynamic LDS stays under the 64 KB a launch gets without raising the kernel's cap: the 32-line block needs 32 (N + N / 8 + 1) floats
+    // = 73.9 KB at N = 512 -- larger images take the 8-line block, 18.5 KB there)
+    constexpr size_t LDS_CAP = 64 * 1024;
+    if (N % KDIP_BLUR_LPB_WIDE == 0 && planes * (N / KDIP_BLUR_LPB_WIDE) >= 1024 && sizeof(float) * KDIP_BLUR_LPB_WIDE * (N + N / 8 + 1) <= LDS_CAP) {
       constexpr int LW = KDIP_BLUR_LPB_WIDE;
       hipLaunchKernelGGL(blur_sep63_kernel<LW>, dim3(N / LW, (unsigned)planes), dim3(256), sizeof(float) * LW * (N + N / 8 + 1), st, x, k1d, taps, N, axis, out);
       KDIP_LAUNCH_CHECK(); return KDIP_OK;
     }
+    KDIP_REQUIRE(sizeof(float) * L63 * (N + N / 8 + 1) <= LDS_CAP, "blur: N=%d needs more than 64 KB of LDS per block", N);
     hipLaunchKernelGGL(blur_sep63_kernel<L63>, dim3(N / L63, (unsigned)planes), dim3(256), sizeof(float) * L63 * (N + N / 8 + 1), st, x, k1d, taps, N,
                        axis, out);
     KDIP_LAUNCH_CHECK(); return KDIP_OK;
   }
   size_t lds = sizeof(float) * (LPB * (N + 1) + taps);
+  KDIP_REQUIRE(lds <= 64 * 1024, "blur: N=%d needs more than 64 KB of LDS per block", N);
   hipLaunchKernelGGL(blur_sep_kernel<LPB>, dim3(N / LPB, (unsigned)planes), dim3(256), lds, st, x, k1d, taps, N, axis, out);
   KDIP_LAUNCH_CHECK(); return KDIP_OK;
 }
@@ -361,7 +366,8 @@ int resize_axis_adj(hipStream_t st, const float* g, const float* w, const int* f
 
 // --------------------------------------------------------------------- Haar DWT ----
 // One thread = one 8x8 input block = all three levels in registers; Mallat layout
-// (pywt coeffs_to_array: cA3 top-left; per level 'da' top-right, 'ad' bottom-left, 'dd' bottom-right).
+// (pywt coeffs_to_array places by key: cA3 top-left; per level 'ad' TOP-RIGHT, 'da' BOTTOM-LEFT, 'dd' bottom-right -- put_sub / get_sub below;
+// pinned against PyWavelets 1.1.1, tests/test_thirdparty_pins.py).
 #define HS_ 0.70710678118654752440f
 template <int S>
 __device__ inline void haar_step(const float (&x)[2 * S][2 * S], float (&aa)[S][S], float (&da)[S][S], float (&ad)[S][S],

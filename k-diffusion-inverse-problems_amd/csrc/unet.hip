@@ -264,7 +264,7 @@ int UNet::finalize() {
     x3_sat = (unsigned*)upload(&zero, sizeof(zero));
   }
   if (rc) return rc;
-  x3_weight_sat = x3_weight_saturations() - x3_w0;      // (packing of one handle runs on one host thread; concurrent finalizes may over-count, never under-count)
+  x3_weight_sat = x3_weight_saturations() - x3_w0;      // (thread-local counter: exactly this handle's weights)
   raw.clear();
   finalized = true;
   return KDIP_OK;
@@ -295,7 +295,11 @@ size_t det_gn_bytes(int B, long HW) {      // gn_stats / gn_bwd_stats: [B][chunk
   return (size_t)B * (chunks + 1) * 64 * sizeof(double);
 }
 size_t det_conv_bytes(int B, int H, int W, int Cout) {      // fused conv statistics: [tiles of 128 pixels][Cout / 4 vectors][2] floats
-  return (size_t)B * (((long)H * W + 127) / 128) * ((Cout + 127) / 128 * 128 / 4) * 2 * sizeof(float);
+  // launch_cfg2 counts tiles from its TH x TW patch geometry (tilesX * tilesY, TH * TW = 128): for maps whose sides are not both
+  // multiples of the patch sides that is more than ceil(HW / 128) -- bounded by cdiv(H, 8) * cdiv(W, 16) and by 2 ceil(HW / 128) + ...;
+  // take the patch-geometry bound (equal to HW / 128 for every power-of-two map the kernels accept today)
+  const long tiles = std::max<long>(((long)H * W + 127) / 128, (long)cdiv(H, 8) * cdiv(W, 16));
+  return (size_t)B * tiles * ((Cout + 127) / 128 * 128 / 4) * 2 * sizeof(float);
 }
 
 // pool_W > 0: y / pool_x receive the 2x2-average-pooled activated / raw tensors instead (downsampling ResBlock)
@@ -653,15 +657,17 @@ int UNet::forward_impl(hipStream_t st, const float* x_nchw, const float* t, int 
   persist.reset(); scratch.reset(); zeros.reset(); fused_stats.clear();
   if (!dry && zeros.cap) KDIP_HIP_CHECK(hipMemsetAsync(zeros.base, 0, zeros.cap, st));
   {
-    // split-K workspace: room for any conv output on a <= 16x16 map (the layers whose launches cannot fill the chip)
+    // split-K workspace: room for any 3x3 conv output (forward: cout, dgrad: cin channels) on a <= 16x16 map (the layers whose launches
+    // cannot fill the chip).  Only the 3x3 convs split K (conv.hip, launch_cfg2): the 3 x cin channels of the attention qkv 1x1 convs
+    // do not count (they used to: 1.5 x the workspace of the FFHQ architecture).
     int maxc = 0;
-    auto upd = [&](const std::vector<Layer>& ls) { for (auto& L : ls) { maxc = std::max(maxc, std::max(L.cin, L.cout)); if (L.kind == 2) maxc = std::max(maxc, 3 * L.cin); } };
+    auto upd = [&](const std::vector<Layer>& ls) { for (auto& L : ls) if (L.kind != 2) maxc = std::max(maxc, std::max(L.cin, L.cout)); };
     for (auto& b : inp) upd(b);
     upd(mid);
     for (auto& b : out) upd(b);
     if (det) {
       // deterministic modes: one slab per K split, plain stores, nothing to keep zeroed (persist arena: lives through the VJP too)
-      sk_ws_floats = (long)B * 256 * maxc * 16;      // 16 = KDIP_SPLITK_MAX (conv.hip)
+      sk_ws_floats = (long)B * 256 * maxc * KDIP_SPLITK_MAX;
       sk_ws = (float*)persist.alloc(sizeof(float) * sk_ws_floats);
     } else {
       sk_ws_floats = (long)B * 256 * maxc;

@@ -41,10 +41,16 @@ class GuidedDenoiser:
         self.v2 = v2
         self.D = tables or DiffusionTables()
         self.cg_stats = {}
-        # test aid: gradient mask of the x0 clamp imposed by the caller (bool tensor) -- for pixels whose |x0_raw| equals 1 to
-        # within rounding either side of the mask is a correct answer, and the two differ by O(1) in the guided output
-        self.clamp_mask_override = None
+        # The guided output is DISCONTINUOUS in the UNet output where |x0_raw| crosses 1 (the VJP goes through the clamp,
+        # condition.py:231): a pixel whose |x0_raw| equals 1 to within rounding has two correct answers that differ by O(1) over its
+        # receptive field.  The oracle owns the set of such pixels: `last_borderline` lists the indices with | |x0_raw| - 1 | <
+        # clamp_borderline_tol in ITS OWN x0_raw.  `clamp_flip` (a list of index tuples) asks for the answer with the clamp-gradient
+        # mask flipped at those pixels; a listed pixel that is not borderline by the oracle's own numbers is refused.  Nothing else
+        # of a run under test can reach the oracle.
+        self.clamp_flip = None
+        self.clamp_borderline_tol = 1e-4
         self.last_x0_raw = None
+        self.last_borderline = []
 
     # ------------------------------------------------------------- uncond ----
     def uncond_pred(self, x, sigma):
@@ -67,8 +73,16 @@ class GuidedDenoiser:
                   - _bc(D.f32(D.sqrt_recipm1_alphas_cumprod, t), x) * eps)
         self.last_x0_raw = x0_raw.detach()
         x0_mean = x0_raw.clamp(-1, 1)                                                      # :293-311,328-333
-        if self.clamp_mask_override is not None:
-            x0_mean = torch.where(self.clamp_mask_override, x0_raw, x0_mean.detach())
+        near = (x0_raw.detach().abs() - 1).abs() < self.clamp_borderline_tol
+        self.last_borderline = [tuple(i) for i in near.nonzero().tolist()]
+        if self.clamp_flip:
+            mask = x0_raw.detach().abs() <= 1
+            for idx in self.clamp_flip:
+                idx = tuple(int(v) for v in idx)
+                if not bool(near[idx]):
+                    raise ValueError(f"clamp_flip: pixel {idx} is not borderline in the oracle's own x0_raw ({float(x0_raw.detach()[idx])!r})")
+                mask[idx] = ~mask[idx]
+            x0_mean = torch.where(mask, x0_raw, x0_mean.detach())      # same values, the flipped gradient mask
         ct = self.x0_cov_type
         base = s0.pow(2) / (1 + s0.pow(2))
         if ct == "convert":

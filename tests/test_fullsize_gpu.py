@@ -33,17 +33,33 @@ def _setup(cfg_name, op_name, dtype, B=1, out_cov=False):
     return m, sd, ocfg, hop, oop, meas, x0
 
 
-def _oracle_with_hip_mask(oden, hip_raw, x, sigma):
-    """Oracle guided call with the HIP run's clamp-gradient mask imposed (pixels with |x0_raw| = 1 to within rounding have two correct
-    answers: test_imagenet_motion_typeI_analytic_fullsize).  The HIP parity modes are deterministic, so the set of such pixels is FIXED for a
-    given build and input; it is returned (and printed by the callers) as a reviewable list, and bounded: <= 4 pixels, each within 1e-4
-    of the boundary."""
-    oden.clamp_mask_override = hip_raw.abs() <= 1
-    ref = oden(x, sigma)
-    flips = (oden.last_x0_raw.abs() <= 1) != oden.clamp_mask_override
-    idx = flips.nonzero().tolist()
-    assert len(idx) <= 4 and (not idx or float((oden.last_x0_raw[flips].abs() - 1).abs().max()) < 1e-4), idx
-    return ref, [(tuple(i), float(oden.last_x0_raw[tuple(i)])) for i in idx]
+def _oracle_admissible(oden, hip_raw, hat, x, sigma):
+    """The oracle's answer(s) for one guided call, and the distance of the HIP output `hat` to the nearest of them.
+
+    The guided output is DISCONTINUOUS where |x0_raw| crosses 1 (VJP through `pred_xstart.clamp(-1, 1)`, condition.py:231,
+    gaussian_diffusion.py:293-311): a pixel with |x0_raw| = 1 to within rounding has two correct answers.  The oracle first answers
+    with ITS OWN clamp mask -- nothing of the HIP run reaches it.  Only if the HIP run's mask differs is a second oracle answer
+    computed, with the oracle's mask flipped at exactly the differing pixels; the oracle itself refuses any pixel that is not within
+    1e-4 of the boundary in its own x0_raw (oracle/condition.py: clamp_flip), and at most 4 pixels may differ.  The HIP output must
+    equal one of the two answers.  Returns (reference nearest to hat, max-abs error against it, [(pixel, oracle x0_raw)] flipped)."""
+    oden.clamp_flip = None
+    ref_own = oden(x, sigma)
+    own_raw = oden.last_x0_raw.clone()
+    err_own = float((hat - ref_own).abs().max())
+    differ = (hip_raw.abs() <= 1) != (own_raw.abs() <= 1)
+    idx = [tuple(i) for i in differ.nonzero().tolist()]
+    if not idx:
+        return ref_own, err_own, []
+    assert len(idx) <= 4, idx
+    assert set(idx) <= set(oden.last_borderline), (idx, oden.last_borderline)
+    oden.clamp_flip = idx
+    try:
+        ref_flip = oden(x, sigma)
+    finally:
+        oden.clamp_flip = None
+    err_flip = float((hat - ref_flip).abs().max())
+    flips = [(i, float(own_raw[i])) for i in idx]
+    return (ref_flip, err_flip, flips) if err_flip <= err_own else (ref_own, err_own, flips)
 
 
 @pytest.mark.parametrize("sigma_v", [1.5, 0.12])
@@ -68,8 +84,7 @@ def test_ffhq_type1_convert_fullsize(sigma_v):
         hm = kc.ConditionOpenAIDenoiser(inner_model=m, diffusion=D, x0_cov_type="convert", recon_mse=None, operator=hop,
                                         measurement=measd, guidance="I", device="cuda")
         hat = hm(x.cuda(), torch.tensor([sigma_v], device="cuda")).cpu()
-        ref, flips = _oracle_with_hip_mask(oden, hm._stash[0].cpu(), x, torch.tensor([sigma_v]))
-        errs[dtype] = float((hat - ref).abs().max())
+        ref, errs[dtype], flips = _oracle_admissible(oden, hm._stash[0].cpu(), hat, x, torch.tensor([sigma_v]))
         print(f"\nFFHQ configs[1] full-size sigma={sigma_v} {dtype}: max-abs {errs[dtype]:.2e}; borderline clamp pixels {flips}")
         if dtype == "f32":
             ref32 = ref
@@ -133,33 +148,19 @@ def test_imagenet_motion_typeI_analytic_fullsize(sigma_v):
     rmd = {k: v.cuda() for k, v in rm.items()}
     hm = kc.ConditionOpenAIDenoiser(inner_model=m, diffusion=D, x0_cov_type="analytic", recon_mse=rmd, operator=hop,
                                     measurement=measd, guidance="I", device="cuda")
-    # The guided output is DISCONTINUOUS in the UNet output where |x0_raw| crosses 1: the VJP goes through clamp(-1, 1)
-    # (condition.py:231 `pred_xstart.clamp`), whose gradient mask flips.  With this input one pixel of image 0 has
-    # x0_raw = -1 +- 2e-6, inside the run-to-run noise of the fp32 split-K atomics: either side of the mask is then a correct
-    # answer and the two differ by O(1) over that pixel's receptive field.  The oracle is therefore run with the HIP path's
-    # mask; the test asserts that the two masks only disagree at such borderline pixels.
+    # (borderline |x0_raw| = 1 pixels have two correct answers: _oracle_admissible; with this input one pixel of image 0 has x0_raw = -1 +- 2e-6)
     x = x0 + sigma_v * torch.randn(2, 3, 256, 256, generator=torch.Generator().manual_seed(11))
     hat = hm(x.cuda(), torch.full((2,), sigma_v, device="cuda")).cpu()
-    hip_raw = hm._stash[0].cpu()
     oden = ocond.GuidedDenoiser(sd, ocfg, oop, meas, "I", x0_cov_type="analytic", recon_mse=rm)
-    oden.clamp_mask_override = hip_raw.abs() <= 1
-    ref = oden(x, torch.full((2,), sigma_v))
-    flips = (oden.last_x0_raw.abs() <= 1) != oden.clamp_mask_override
-    assert int(flips.sum()) <= 4 and (not flips.any() or float((oden.last_x0_raw[flips].abs() - 1).abs().max()) < 1e-4)
-    err = float((hat - ref).abs().max())
+    ref, err, flips = _oracle_admissible(oden, hm._stash[0].cpu(), hat, x, torch.full((2,), sigma_v))
     del m, hm
     torch.cuda.empty_cache()
     m3 = ku.UNetModel(dtype="bf16x3", **ku.IMAGENET_CONFIG); m3.load_state_dict(sd)
     hm3 = kc.ConditionOpenAIDenoiser(inner_model=m3, diffusion=D, x0_cov_type="analytic", recon_mse=rmd, operator=hop,
                                      measurement=measd, guidance="I", device="cuda")
     hat3 = hm3(x.cuda(), torch.full((2,), sigma_v, device="cuda")).cpu()
-    # (its own borderline pixels: the oracle is given THIS run's clamp mask, as for the f32 run above)
-    oden.clamp_mask_override = hm3._stash[0].cpu().abs() <= 1
-    ref3 = oden(x, torch.full((2,), sigma_v))
-    flips3 = (oden.last_x0_raw.abs() <= 1) != oden.clamp_mask_override
-    assert int(flips3.sum()) <= 4 and (not flips3.any() or float((oden.last_x0_raw[flips3].abs() - 1).abs().max()) < 1e-4)
-    err3 = float((hat3 - ref3).abs().max())
-    print(f"\nconfigs[3] sigma={sigma_v}: bf16x3 max-abs {err3:.2e} ({int(flips3.sum())} borderline clamp pixels)")
+    ref3, err3, flips3 = _oracle_admissible(oden, hm3._stash[0].cpu(), hat3, x, torch.full((2,), sigma_v))
+    print(f"\nconfigs[3] sigma={sigma_v}: bf16x3 max-abs {err3:.2e} (borderline clamp pixels flipped: {flips3})")
     assert err3 < 2e-3, err3                 # the split-precision mode at the f32 bound
     del m3, hm3
     torch.cuda.empty_cache()
@@ -168,7 +169,7 @@ def test_imagenet_motion_typeI_analytic_fullsize(sigma_v):
                                      measurement=measd, guidance="I", device="cuda")
     hat2 = hm2(x.cuda(), torch.full((2,), sigma_v, device="cuda")).cpu()
     p = psnr_db(hat2, ref)
-    print(f"\nconfigs[3] ImageNet motion Type-I analytic sigma={sigma_v} B=2 ({int(flips.sum())} borderline clamp pixels): f32 max-abs {err:.2e}; bf16 PSNR(hip, oracle) {p:.1f} dB, "
+    print(f"\nconfigs[3] ImageNet motion Type-I analytic sigma={sigma_v} B=2 (borderline clamp pixels flipped: {flips}): f32 max-abs {err:.2e}; bf16 PSNR(hip, oracle) {p:.1f} dB, "
           f"bf16 max-abs {float((hat2 - ref).abs().max()):.2e}")
     assert err < 2e-3, err
     assert torch.isfinite(hat2).all() and p > (25.0 if sigma_v > 1 else 61.0)      # measured 30.4 dB (sigma 1.5: clamp flips on saturated random-weight outputs) / 66.9 dB (sigma 0.12); floor = measured - 5 dB
@@ -224,19 +225,18 @@ def test_baseline_configs_fullsize_vs_oracle(cid, opn, guid, cov, extra, ortho, 
             oden = ocond.GuidedDenoiser(sd, ocfg, oop, meas, guid, x0_cov_type=cov, zeta=extra.get("zeta"))
         else:
             oden = ocond.GuidedDenoiser(sd, ocfg, oop, meas, guid, mle_sigma_thres=1.0, v2=True, ortho_tf_type=ortho)
-        flips = 0
-        if raw is not None:      # borderline |x0_raw| = 1 pixels have two correct answers (see test_imagenet_motion_typeI_analytic_fullsize)
-            oden.clamp_mask_override = raw.abs() <= 1
-        ref = oden(x, torch.full((B,), sigma_v))
-        if raw is not None:
-            fl = (oden.last_x0_raw.abs() <= 1) != oden.clamp_mask_override
-            flips = int(fl.sum())
-            assert flips <= 4 and (flips == 0 or float((oden.last_x0_raw[fl].abs() - 1).abs().max()) < 1e-4)
-        e32 = float((hat - ref).abs().max())
-        ex3 = float((outs[("bf16x3", sigma_v)][1] - ref).abs().max())
+        flips = []
+        if raw is not None:      # V1 paths with a VJP through the clamp: borderline |x0_raw| = 1 pixels have two correct answers (_oracle_admissible)
+            ref, e32, flips = _oracle_admissible(oden, raw, hat, x, torch.full((B,), sigma_v))
+            _, ex3, fl3 = _oracle_admissible(oden, outs[("bf16x3", sigma_v)][2], outs[("bf16x3", sigma_v)][1], x, torch.full((B,), sigma_v))
+            flips = flips + fl3
+        else:
+            ref = oden(x, torch.full((B,), sigma_v))
+            e32 = float((hat - ref).abs().max())
+            ex3 = float((outs[("bf16x3", sigma_v)][1] - ref).abs().max())
         p16 = psnr_db(outs[("bf16", sigma_v)][1], ref)
         iters = f", oracle CG iterations {oden.cg_stats.get('iters')}" if oden.cg_stats.get("iters") is not None else ""
-        print(f"\n{cid} sigma={sigma_v} B={B} ({flips} borderline clamp pixels{iters}): f32 max-abs {e32:.2e}; bf16x3 max-abs {ex3:.2e}; bf16 PSNR(hip, oracle) {p16:.1f} dB")
+        print(f"\n{cid} sigma={sigma_v} B={B} (borderline clamp pixels flipped: {flips}{iters}): f32 max-abs {e32:.2e}; bf16x3 max-abs {ex3:.2e}; bf16 PSNR(hip, oracle) {p16:.1f} dB")
         assert e32 < 2e-4 and ex3 < 2e-4, (cid, sigma_v, e32, ex3)       # measured <= 6.7e-5 (f32) / 6.0e-5 (bf16x3)
         assert p16 > BF16_FLOOR[(cid, sigma_v > 1)], (cid, sigma_v, p16)
 
@@ -301,10 +301,15 @@ def test_e2e_teacher_forced(opn, guid, cov, extra):
     model call's input (x_i, sigma_i) is recorded; bf16x3 and bf16 are then evaluated on those SAME inputs and compared call by call
     with the teacher's outputs.  (A free-running comparison of two trajectories carries no information with random weights: the
     Type-I ODE is chaotic and two runs of one arithmetic land 20 - 40 dB apart -- DESIGN.md section 3; those numbers are only printed.)
-      bf16x3: max-abs <= 2e-4 on every call (the bound of the full-size oracle comparisons above).  The guided output is discontinuous
+      bf16x3: max-abs <= 1e-4 x max(2, sigma^2) on every call (2e-4, the bound of the full-size oracle comparisons above, up to sigma 1.4;
+              the sigma^2 amplification of the guidance term above: 0.64 at sigma 80, measured 7.8e-2) AND per-call PSNR(bf16x3, f32) > 65 dB
+              -- the PSNR floor is the effective guard at high sigma.  The guided output is discontinuous
               where |x0_raw| crosses 1 (VJP through clamp, condition.py:231), so calls whose clamp mask differs from the teacher's are
               re-evaluated with the teacher's mask imposed (stepwise path) after checking that the masks differ only at pixels within
               1e-4 x max(1, sigma / 5) of the boundary.
+              The two non-chaotic runs (super-resolution Type-II, inpainting DPS) also assert the north_star tolerance end to end on the
+              FREE-RUNNING trajectory: |PSNR_bf16x3 - PSNR_f32| < 1e-3 dB per image against the ground truth (measured 5e-7 / 2e-6 dB;
+              both modes are bitwise reproducible).  The 100-step version of that assertion is test_e2e_100_steps_bf16x3_vs_f32_config2.
       bf16:   per-call PSNR(bf16, f32) floors, stated above.
     Recorded in gpurun_out/e2e_teacher_forced.jsonl."""
     import json, os
@@ -369,9 +374,13 @@ def test_e2e_teacher_forced(opn, guid, cov, extra):
         print(f"  free-running {dtype}: PSNR vs GT {p} (f32 {p_f32}), |dPSNR| {dp:.2e} dB, PSNR({dtype}, f32) {psnr_db(free, out_f32):.1f} dB  [diagnostic]")
         rec[dtype] = {"sigma": sigs, "call_max_abs": errs, "call_psnr_db": psnrs, "clamp_flips": flips_total, "forced_calls": forced_calls,
                       "free_running_psnr_vs_gt": p, "free_running_abs_dpsnr_db": dp}
+        if dtype == "bf16x3" and opn in ("super_resolution", "inpainting"):
+            free_dp = dp      # asserted below (after the record is written)
     os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
     with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "e2e_teacher_forced.jsonl"), "a") as f:
         f.write(json.dumps(rec) + "\n")
+    if opn in ("super_resolution", "inpainting"):
+        assert free_dp < 1e-3, (opn, free_dp)       # north_star: within 1e-3 dB PSNR end to end (20 Heun steps, free-running)
     for dtype, sigs, errs, psnrs in checks:
         for sg, e, pp in zip(sigs, errs, psnrs):
             if dtype == "bf16x3":
