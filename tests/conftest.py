@@ -18,7 +18,7 @@ def pytest_configure(config):
 # deterministic and carry the parity claim --, kernel unit tests next, the full-size oracle comparisons after that, the long
 # sampler runs last, so that a late failure can never hide the golden comparisons.
 _FILE_ORDER = ["test_oracle_golden", "test_thirdparty_pins", "test_host_cpu", "test_parity_gpu", "test_mid_gpu", "test_kernels_gpu", "test_x3_gpu",
-               "test_harness_gpu", "test_conv3_gpu", "test_attention_gpu", "test_determinism_gpu", "test_fullsize_gpu",
+               "test_harness_gpu", "test_conv3_gpu", "test_attention_gpu", "test_determinism_gpu", "test_fullsize_gpu", "test_configs_b16_gpu",
                "test_multigpu"]
 _LATE_TESTS = ("test_e2e_", "test_baseline_config_shapes_run")
 
