@@ -142,11 +142,15 @@ struct ConvParams {
   //   st_mode 1: sums[b][g] += (sum y, sum y^2)                         -> next GroupNorm forward
   //   st_mode 2: y is dL/d(GN-apply output); with x = the GN input, z = a*x + b:
   //              sums[b][g] += (sum a*dz, sum a*dz*xhat), dz = y * silu'(z) | y   -> GroupNorm backward
+  //   st_mode 3 (fp32 storage): no statistics -- GroupNorm-backward apply folded into the epilogue: y = acc + a*dz - (k0 + k1*gx) (+ add)  (ConvStats::gnb_*)
   int st_mode, st_silu;
+  int st_store_dz;                // mode 2, fp32 storage: the sweep overwrites the stored dy with dz = dy * silu'(z)
+  const float* gnb_coef; const void* gnb_dz; long gnb_lddz; const void* gnb_x; long gnb_ldx; const void* gnb_add; long gnb_lda; int gnb_silu;
   double* st_sums;                // [B][32][2], pre-zeroed
   const void* st_x; long st_ldx;  // mode 2
   const float* st_coef;           // mode 2: [B][Cout][2] (a, b)
   const float* st_mr;             // mode 2: [B][32][2] (mean, rstd)
+  const void* tf_x2; int tf_mode;      // tf_mode 2: GroupNorm BACKWARD apply while staging: A = a*x - (k0 + k1*x2), tf_coef [B][Cin][4] = (a, b, k0, k1), x2 shares x's layout
   const float* tf_coef; int tf_silu;   // split precision, 3x3: the input is a GroupNorm INPUT; silu?(a*x + b) with (a, b) = tf_coef[B][Cin][2] is applied while
                                   // the patch is staged (conv zero padding applies to the transformed tensor); one image per tile only
   float* det_slab; size_t det_slab_bytes;   // deterministic modes (det.h): fused statistics go block by block into det_slab [B][tiles per image][n-blocks][BN/4][2] and are
@@ -272,6 +276,12 @@ static_assert(KDIP_SPLITK_MAX >= 1 && KDIP_SPLITK_MAX <= 64, "KDIP_SPLITK_MAX (k
 #ifndef KDIP_X3_SUBS1
 #define KDIP_X3_SUBS1 1      // split-precision 1x1 convs: 32-channel sub-chunks staged per barrier (2 = 102 KB of LDS, one block per CU: 404 vs 249 us
                              // on the 128 -> 256 @ 256x256 skip conv)
+#endif
+#ifndef KDIP_X3_SUBS1_SMALL
+#define KDIP_X3_SUBS1_SMALL 1
+#endif
+#ifndef KDIP_X3_LAYOUT14
+#define KDIP_X3_LAYOUT14 0   // 1: the split-precision 128 x 128 3x3 tile as 1 x 4 waves of 128 px x 32 co (no weight fragment is fetched or re-encoded twice; every wave reads all A fragments)
 #endif
 #ifndef KDIP_X3_B_DEPTH
 #define KDIP_X3_B_DEPTH 2    // ... and the weight-fragment stages in flight of their 3x3 instantiations (two 16-byte planes per fragment): 2 measured
@@ -557,6 +567,17 @@ __device__ __forceinline__ void epilogue_f32_fast(const ConvParams& p, f32x16 (&
   constexpr bool FOLD2 = MODE == 2 && KDIP_EPI32_FOLD2;
   float ca[4] = {0.f, 0.f, 0.f, 0.f}, cb[4] = {0.f, 0.f, 0.f, 0.f};
   float2 mrv = make_float2(0.f, 0.f);
+  // MODE 3: GroupNorm-backward apply folded into the epilogue (ConvStats::gnb_*): out = acc + a*dz - (k0 + k1*gx) (+ add).  The dz / gx / add rows
+  // of HALF an m-tile are requested before the transpose (the other half's behind the first half's stores): 3 x NPASS / 2 vectors in flight
+  float gk0[4] = {0.f, 0.f, 0.f, 0.f}, gk1[4] = {0.f, 0.f, 0.f, 0.f};
+  const float* gdz = (const float*)p.gnb_dz;
+  const float* ggx = (const float*)p.gnb_x;
+  const float* gadd = (const float*)p.gnb_add;
+  if (MODE == 3) {
+    const float4* kc = (const float4*)p.gnb_coef + ((long)img0 * p.Cout + nl);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float4 c = kc[e]; ca[e] = c.x; cb[e] = c.y; gk0[e] = c.z; gk1[e] = c.w; }
+  }
   if (FOLD2) {
     const float4* cf = (const float4*)(p.st_coef + ((long)img0 * p.Cout + nl) * 2);
     const float4 c0 = cf[0], c1 = cf[1];
@@ -588,6 +609,36 @@ __device__ __forceinline__ void epilogue_f32_fast(const ConvParams& p, f32x16 (&
         *(float*)(creg + row * RS + (nt * 32 + (lane & 31)) * 4) = acc[mt][nt][r] * alpha + bv[nt];
       }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if constexpr (MODE == 3) {
+      constexpr int HB = NPASS >= 2 ? NPASS / 2 : 1;
+#pragma unroll
+      for (int h0 = 0; h0 < NPASS; h0 += HB) {
+        float4 rz[HB], rx[HB], ra[HB];
+#pragma unroll
+        for (int j = 0; j < HB; ++j) {
+          rz[j] = *(const float4*)(gdz + (long)pix[h0 + j] * p.gnb_lddz + nl);
+          rx[j] = *(const float4*)(ggx + (long)pix[h0 + j] * p.gnb_ldx + nl);
+          ra[j] = gadd ? *(const float4*)(gadd + (long)pix[h0 + j] * p.gnb_lda + nl) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < HB; ++j) {
+          const int row = (h0 + j) * RPI + rowl;
+          float4 v = *(const float4*)(creg + row * RS + vec * 16);
+          if (RES) { v.x += rres[h0 + j].x; v.y += rres[h0 + j].y; v.z += rres[h0 + j].z; v.w += rres[h0 + j].w; }
+          // the same operation order as gn_bwd_apply_kernel (norm.hip): r = a*dz - (k0 + k1*x); r += skip gradient; r += concat gradient
+          float4 r;
+          if (p.gnb_silu) {                                // (uniform) the tensor holds dy: dz = dy * silu'(a*x + b), as gn_bwd_apply_kernel forms it
+            rz[j].x *= silu_grad_f(ca[0] * rx[j].x + cb[0]); rz[j].y *= silu_grad_f(ca[1] * rx[j].y + cb[1]);
+            rz[j].z *= silu_grad_f(ca[2] * rx[j].z + cb[2]); rz[j].w *= silu_grad_f(ca[3] * rx[j].w + cb[3]);
+          }
+          r.x = ca[0] * rz[j].x - (gk0[0] + gk1[0] * rx[j].x); r.y = ca[1] * rz[j].y - (gk0[1] + gk1[1] * rx[j].y);
+          r.z = ca[2] * rz[j].z - (gk0[2] + gk1[2] * rx[j].z); r.w = ca[3] * rz[j].w - (gk0[3] + gk1[3] * rx[j].w);
+          r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w;
+          if (gadd) { r.x += ra[j].x; r.y += ra[j].y; r.z += ra[j].z; r.w += ra[j].w; }
+          *(float4*)(yout + (long)pix[h0 + j] * p.ldy + nl) = r;
+        }
+      }
+    } else {
 #pragma unroll
     for (int it = 0; it < NPASS; ++it) {
       const int row = it * RPI + rowl;
@@ -600,15 +651,19 @@ __device__ __forceinline__ void epilogue_f32_fast(const ConvParams& p, f32x16 (&
       }
       if (FOLD2 && !RES) {
         const float vv[4] = {v.x, v.y, v.z, v.w}, xv[4] = {rres[it].x, rres[it].y, rres[it].z, rres[it].w};
+        float dzv[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float z = ca[e] * xv[e] + cb[e];
           const float dz = p.st_silu ? vv[e] * silu_grad_f(z) : vv[e];
+          dzv[e] = dz;
           const float adz = ca[e] * dz;
           s1 += adz;
           s2 += adz * (xv[e] - mrv.x) * mrv.y;
         }
+        if (p.st_store_dz) *(float4*)(yout + (long)pix[it] * p.ldy + nl) = make_float4(dzv[0], dzv[1], dzv[2], dzv[3]);
       }
+    }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
@@ -625,42 +680,49 @@ __device__ __forceinline__ void epilogue_f32_fast(const ConvParams& p, f32x16 (&
 #pragma unroll 1
     for (int q0 = 0; q0 < MT * NPASS; q0 += SB) {
       float4 rd[SB], rx[SB];
+      int pxs[SB];
 #pragma unroll
       for (int j = 0; j < SB; ++j) {
         const int m = wm * MT * 32 + (q0 + j) * RPI + rowl;
         const int tb = m >> p.lgTHW, rr = m & ((1 << p.lgTHW) - 1);
         const int ty = rr >> p.lgTW, tx = rr & (p.TW - 1);
         const long px = ((long)(img0 + tb) * p.H + (y0 + ty)) * p.W + (x0 + tx);
+        pxs[j] = (int)px;
         rd[j] = *(const float4*)(yout + px * p.ldy + nl);
         rx[j] = *(const float4*)(sx + px * p.st_ldx + nl);
       }
 #pragma unroll
       for (int j = 0; j < SB; ++j) {
         const float vv[4] = {rd[j].x, rd[j].y, rd[j].z, rd[j].w}, xv[4] = {rx[j].x, rx[j].y, rx[j].z, rx[j].w};
+        float dzv[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float z = ca[e] * xv[e] + cb[e];
           const float dz = p.st_silu ? vv[e] * silu_grad_f(z) : vv[e];
+          dzv[e] = dz;
           const float adz = ca[e] * dz;
           s1 += adz;
           s2 += adz * (xv[e] - mrv.x) * mrv.y;
         }
+        // (ConvStats::store_dz) the tensor leaves as dz: the lane overwrites exactly the values it stored itself (L2-hot lines)
+        if (p.st_store_dz) *(float4*)(yout + (long)pxs[j] * p.ldy + nl) = make_float4(dzv[0], dzv[1], dzv[2], dzv[3]);
       }
     }
   }
-  if (MODE) {
+  if (MODE == 1 || MODE == 2) {
     // rows -> lanes sharing `vec` (xor butterfly: the same additions in every run), then the block-level combine
 #pragma unroll
     for (int o = LPR; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
     conv_stats_handover<WAVES_M, BN, LPR>(p, s1, s2, sred, tid, lane, wm, wn, ntb, nblkN, img0, trem, tpi);
   }
-  (void)cpg;
+  (void)cpg; (void)gk0; (void)gk1; (void)gdz; (void)ggx; (void)gadd;
 }
 
 // SUBS = 32-channel sub-chunks staged in LDS per barrier (1 for 3x3; up to 4 for 1x1 so a barrier
 // covers 32 MFMAs per wave instead of 8).
 // TFM 1 (split precision, 3x3 only): the staging transform of ConvParams::tf_coef is compiled in (its own instantiation: the
 // transform's registers do not fit next to the two-deep weight pipeline of the plain one)
+// TFM 2: GroupNorm-backward staging of a dgrad conv (two tensors staged: dz and the GroupNorm input; ConvParams::tf_mode 2)
 template <typename T, int NTAPS, int WAVES_M, int WAVES_N, int MT, int NT, int SUBS, int TFM = 0>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::value) ? (MT * NT == 4 ? KDIP_X3_OCC : 2) : (sizeof(T) == 2 && NTAPS == 9) ? (MT * NT == 4 ? KDIP_OCC : (MT * NT == 8 ? 2 : 1)) : ((sizeof(T) == 2 && NTAPS == 1 && MT * NT == 4 && SUBS == 2) ? 3 : 1)) void conv_igemm_kernel(ConvParams p) {
   constexpr bool X3 = std::is_same<T, f32x3_t>::value;     // fp32 storage, operands split into bf16 hi / lo planes on the way into LDS
@@ -828,12 +890,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
   const int nchunks = p.sk_splits > 1 ? (int)((long)nchunks_all * (blockIdx.y + 1) / p.sk_splits) : nchunks_all;   // = c_end
   uint4 areg[MAXV];
   constexpr bool x3_tf = X3 && TFM != 0;
+  constexpr bool x3_tf2 = X3 && TFM == 2;
+  uint4 areg2[x3_tf2 ? MAXV : 1];                     // TFM 2: the GroupNorm-input rows of the same patch pixels
+  const T* xin2 = (const T*)p.tf_x2;
   int tf_chunk = 0;                                    // chunk the staging registers hold
   auto stage_load = [&](int c) {
     tf_chunk = c;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       areg[i] = make_uint4(0, 0, 0, 0);
+      if constexpr (x3_tf2) areg2[i] = make_uint4(0, 0, 0, 0);
       if (goff[i] >= 0) {
         if (KDIP_CONV1_NT_LOAD && NTAPS == 1) {       // 1x1: every input element is read exactly once by this launch
           typedef __attribute__((ext_vector_type(4))) unsigned cu32x4;
@@ -842,6 +908,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
         } else {
           areg[i] = *(const uint4*)(xin + (long)goff[i] * (16 / (int)sizeof(T)) + (long)c * KCH);
         }
+        if constexpr (x3_tf2) areg2[i] = *(const uint4*)(xin2 + (long)goff[i] * (16 / (int)sizeof(T)) + (long)c * KCH);
       }
     }
   };
@@ -849,9 +916,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
     // staging transform: (a, b) of this thread's 4 channels of the staged chunk (thread -> channel group is the same for all its
     // vectors: NTHREADS % VPP == 0); fetched here (L2-hot, 32 bytes) rather than with the patch loads: 8 fewer registers live
     // across the MFMA stages
-    float4 tfk[2] = {make_float4(1.f, 0.f, 1.f, 0.f), make_float4(1.f, 0.f, 1.f, 0.f)};
+    float4 tfk[x3_tf2 ? 4 : 2];
+    tfk[0] = tfk[1] = make_float4(1.f, 0.f, 1.f, 0.f);
     float x3_peak = 0.f;                                 // largest |scaled operand| this thread staged in this chunk
-    if (x3_tf) {
+    if constexpr (x3_tf2) {                              // (a, b, k0, k1) of the thread's 4 channels
+      const float4* cf = (const float4*)(p.tf_coef + ((long)img0 * p.Cin + (long)tf_chunk * KCH + (tid % VPP) * 4) * 4);
+      tfk[0] = cf[0]; tfk[1] = cf[1]; tfk[2] = cf[2]; tfk[3] = cf[3];
+    } else if (x3_tf) {
       const float4* cf = (const float4*)(p.tf_coef + ((long)img0 * p.Cin + (long)tf_chunk * KCH + (tid % VPP) * 4) * 2);
       tfk[0] = cf[0]; tfk[1] = cf[1];
     }
@@ -864,7 +935,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
         if (pix < npix) {
           float f[4];
           unpack16<float>(areg[i], f);
-          if (x3_tf) {                                   // (block-uniform) GroupNorm (+ FiLM) (+ SiLU) of the staged element
+          if constexpr (x3_tf2) {                        // GroupNorm backward: gradient w.r.t. the GroupNorm input from dz and the input itself
+            float g2[4];
+            unpack16<float>(areg2[i], g2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (p.tf_silu) f[e] *= silu_grad_fast(tfk[e].x * g2[e] + tfk[e].y);      // (uniform) the staged tensor holds dy, not dz
+              f[e] = tfk[e].x * f[e] - (tfk[e].z + tfk[e].w * g2[e]);
+            }
+            if (goff[i] < 0) { f[0] = f[1] = f[2] = f[3] = 0.f; }      // zero padding of the TRANSFORMED tensor
+          } else if (x3_tf) {                            // (block-uniform) GroupNorm (+ FiLM) (+ SiLU) of the staged element
             f[0] = tfk[0].x * f[0] + tfk[0].y; f[1] = tfk[0].z * f[1] + tfk[0].w;
             f[2] = tfk[1].x * f[2] + tfk[1].y; f[3] = tfk[1].z * f[3] + tfk[1].w;
             if (p.tf_silu) {
@@ -1077,9 +1157,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
     if (KDIP_FAST_EPI32 && p.fast_epilogue32 && (ntb + 1) * BN <= p.Cout) {     // block-uniform
 #define KDIP_EPI32(R, M) epilogue_f32_fast<WAVES_M, WAVES_N, MT, NT, R, M>(p, acc, alpha, smem, tid, lane, wave, wm, wn, nt0, ntb, img0, y0, x0, nblkN, trem, tpi)
       if (p.res) {
-        if (p.st_mode == 0) KDIP_EPI32(true, 0); else if (p.st_mode == 1) KDIP_EPI32(true, 1); else KDIP_EPI32(true, 2);
+        if (p.st_mode == 0) KDIP_EPI32(true, 0); else if (p.st_mode == 1) KDIP_EPI32(true, 1); else KDIP_EPI32(true, 2);      // (mode 3 never comes with a residual: launch_cfg2)
       } else {
-        if (p.st_mode == 0) KDIP_EPI32(false, 0); else if (p.st_mode == 1) KDIP_EPI32(false, 1); else KDIP_EPI32(false, 2);
+        if (p.st_mode == 0) KDIP_EPI32(false, 0); else if (p.st_mode == 1) KDIP_EPI32(false, 1); else if (p.st_mode == 2) KDIP_EPI32(false, 2);
+        else { if constexpr (NTAPS == 1) KDIP_EPI32(false, 3); }
       }
 #undef KDIP_EPI32
       KDIP_STAMP(3);
@@ -1170,21 +1251,24 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
               float4 xr = *(const float4*)((const float*)p.st_x + pix * p.st_ldx + n);
               xv[0] = xr.x; xv[1] = xr.y; xv[2] = xr.z; xv[3] = xr.w;
             }
+            float dzv[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               float z = ca[e] * xv[e] + cb[e];
               float dz = p.st_silu ? vv[e] * silu_grad_T<T>(z) : vv[e];
+              dzv[e] = dz;
               float adz = ca[e] * dz;
               s1 += adz;
               s2 += adz * (xv[e] - gmean) * grstd;
             }
+            if (sizeof(T) == 4 && p.st_store_dz) *(float4*)((float*)p.y + pix * p.ldy + n) = make_float4(dzv[0], dzv[1], dzv[2], dzv[3]);
           }
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     KDIP_STAMP(4);
-    if (p.st_mode) {
+    if (p.st_mode == 1 || p.st_mode == 2) {
       // rows -> lanes sharing `vec` (xor butterfly), then the block-level combine
 #pragma unroll
       for (int o = LPR; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
@@ -1308,27 +1392,34 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
                     (p.st_mode != 2 || (p.st_ldx % 8 == 0 && (uintptr_t)p.st_x % 16 == 0 && (uintptr_t)p.st_coef % 16 == 0 && (uintptr_t)p.st_mr % 8 == 0));
   p.fast_epilogue32 = sizeof(T) == 4 && p.vec_epilogue && (uintptr_t)p.y % 16 == 0 && (!p.res || (uintptr_t)p.res % 16 == 0) && p.B % TB == 0 &&
                       (p.st_mode != 2 || (p.st_ldx % 4 == 0 && (uintptr_t)p.st_x % 16 == 0 && (uintptr_t)p.st_coef % 16 == 0 && (uintptr_t)p.st_mr % 8 == 0 && ((p.Cout >> 5) % 4) == 0)) &&
-                      (p.st_mode == 0 || ((p.Cout >> 5) % 4) == 0);
-  if (p.st_mode && !(p.vec_epilogue && TB == 1 && p.Cout % 32 == 0 && ((p.Cout >> 5) % 4) == 0))
+                      (p.st_mode == 0 || p.st_mode == 3 || ((p.Cout >> 5) % 4) == 0);
+  if (p.st_mode == 3) {
+    if (!(NTAPS == 1 && sizeof(T) == 4 && KDIP_FAST_EPI32 && p.fast_epilogue32 && TB == 1 && !p.res && !p.out_f32 && p.Cout % BN == 0 && p.gnb_coef && p.gnb_dz && p.gnb_x &&
+          (uintptr_t)p.gnb_coef % 16 == 0 && (uintptr_t)p.gnb_dz % 16 == 0 && (uintptr_t)p.gnb_x % 16 == 0 && (uintptr_t)p.gnb_add % 16 == 0 &&
+          p.gnb_lddz % 4 == 0 && p.gnb_ldx % 4 == 0 && p.gnb_lda % 4 == 0))
+      return set_error(KDIP_ERR_UNSUPPORTED, "conv: GroupNorm-backward epilogue (mode 3) needs an fp32-storage 1x1 conv, one image per tile, Cout %% %d == 0 and 16-byte aligned operands", BN);
+  } else if (p.st_mode && !(p.vec_epilogue && TB == 1 && p.Cout % 32 == 0 && ((p.Cout >> 5) % 4) == 0))
     return set_error(KDIP_ERR_UNSUPPORTED, "conv: fused GroupNorm statistics not available for this shape");
   int nblkN = cdiv(p.ntilesN * 32, BN);
   long grid = (long)p.mtiles * nblkN;
   constexpr bool TF_OK = std::is_same<T, f32x3_t>::value && NTAPS == 9 && SUBS == 1;
   if (p.tf_coef && !(TF_OK && TB == 1)) return set_error(KDIP_ERR_UNSUPPORTED, "conv: fused GroupNorm staging is not available for this shape");
-  auto kern = (TF_OK && p.tf_coef) ? conv_igemm_kernel<T, NTAPS, WAVES_M, WAVES_N, MT, NT, SUBS, (TF_OK ? 1 : 0)> : conv_igemm_kernel<T, NTAPS, WAVES_M, WAVES_N, MT, NT, SUBS, 0>;
+  auto kern = (TF_OK && p.tf_coef) ? (p.tf_mode == 2 ? conv_igemm_kernel<T, NTAPS, WAVES_M, WAVES_N, MT, NT, SUBS, (TF_OK ? 2 : 0)> : conv_igemm_kernel<T, NTAPS, WAVES_M, WAVES_N, MT, NT, SUBS, (TF_OK ? 1 : 0)>)
+                                   : conv_igemm_kernel<T, NTAPS, WAVES_M, WAVES_N, MT, NT, SUBS, 0>;
   p.dbg = (KDIP_TIMING && g_conv_dbg && NTAPS == 9 && p.H == g_dbg_H && p.cin_real == g_dbg_cin && p.Cout == g_dbg_cout &&
            p.st_mode == g_dbg_mode && grid <= 16384) ? g_conv_dbg : nullptr;
   if (g_prof_on) {
     const int cls = (NTAPS == 9 ? 0 : 3) + (BN == 128 ? 0 : (BN == 64 ? 1 : 2));
     const double px = (double)p.B * p.H * p.W;
     prof_begin(st, cls, 2.0 * px * p.cin_real * p.Cout * NTAPS,
-               px * (p.cin_real + p.Cout) * sizeof(T) + (double)NTAPS * p.cin_real * p.Cout * sizeof(T), "conv", p.B, p.H, p.cin_real, p.Cout);
+               px * (p.cin_real + p.Cout * (p.st_mode == 3 ? (p.gnb_add ? 4 : 3) : 1)) * sizeof(T) + (double)NTAPS * p.cin_real * p.Cout * sizeof(T),
+               p.st_mode == 3 ? "conv_gnb" : "conv", p.B, p.H, p.cin_real, p.Cout);
   }
   if (lds > 48 * 1024) {
     // raise the dynamic-LDS cap once per (instantiation, device); the attribute is per device, and launches may come from
     // several host threads (run_on_streams): an atomic device bit mask, setting the attribute twice is harmless
-    static std::atomic<unsigned long long> granted2[2] = {{0}, {0}};       // [plain | staging-transform instantiation]
-    std::atomic<unsigned long long>& granted = granted2[(TF_OK && p.tf_coef) ? 1 : 0];
+    static std::atomic<unsigned long long> granted2[3] = {{0}, {0}, {0}};       // [plain | staging-transform instantiations]
+    std::atomic<unsigned long long>& granted = granted2[(TF_OK && p.tf_coef) ? (p.tf_mode == 2 ? 2 : 1) : 0];
     int dev = 0;
     KDIP_HIP_CHECK(hipGetDevice(&dev));
     const unsigned long long bit = 1ull << (dev & 63);
@@ -1376,7 +1467,7 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
     }
   }
   p.sk_splits = splits;
-  if (p.st_mode && p.det_slab) {
+  if ((p.st_mode == 1 || p.st_mode == 2) && p.det_slab) {
     KDIP_REQUIRE((size_t)p.mtiles * nblkN * (BN / 4) * 2 * sizeof(float) <= p.det_slab_bytes,
                  "conv: deterministic-statistics workspace too small (%d tiles x %d n-blocks)", p.mtiles, nblkN);
   }
@@ -1388,7 +1479,7 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
     hipLaunchKernelGGL(conv_splitk_finalize_kernel<ST>, dim3((unsigned)g), dim3(256), 0, st, p.sk_ws, p.bias, (const ST*)p.res, p.ldr, npix, p.Cout,
                        (ST*)p.y, p.ldy, p.sk_det ? splits : 0);
   }
-  if (p.st_mode && p.det_slab) {
+  if ((p.st_mode == 1 || p.st_mode == 2) && p.det_slab) {
     const int NV = nblkN * (BN / 4);
     hipLaunchKernelGGL(conv_stats_finish_kernel, dim3(p.B), dim3(256), (size_t)NV * 2 * sizeof(double), st, (const float2*)p.det_slab, p.tilesX * p.tilesY, NV,
                        p.Cout >> 5, p.st_sums);
@@ -1407,6 +1498,10 @@ static int launch_cfg(ConvParams& p, hipStream_t st) {
     if (sizeof(T) == 2 && MT * NT == 4 && p.Cin % 64 == 0) return launch_cfg2<T, NTAPS, WAVES_M, WAVES_N, MT, NT, (NTAPS == 1 ? 2 : 1)>(p, st);
     if (KDIP_SUBS1 >= 4 && sizeof(T) == 2 && p.Cin % 128 == 0) return launch_cfg2<T, NTAPS, WAVES_M, WAVES_N, MT, NT, (NTAPS == 1 ? 4 : 1)>(p, st);
     if (KDIP_SUBS1 >= 2 && sizeof(T) == 2 && p.Cin % 64 == 0) return launch_cfg2<T, NTAPS, WAVES_M, WAVES_N, MT, NT, (NTAPS == 1 ? 2 : 1)>(p, st);
+    // split precision, 128 x 32 tile (small maps): the staging runs ONE chunk ahead, so a K loop of Cin / 32 chunks is a chain of Cin / 32 memory
+    // round trips (16^2 1024 -> 512: 32 us for 2 GFLOP); 64-channel chunks halve the chain (102 KB of LDS: one block per CU, which is all
+    // these launches have anyway)
+    if (KDIP_X3_SUBS1_SMALL >= 2 && std::is_same<T, f32x3_t>::value && MT * NT == 1 && p.Cin % 64 == 0) return launch_cfg2<T, NTAPS, WAVES_M, WAVES_N, MT, NT, (NTAPS == 1 ? 2 : 1)>(p, st);
     // split precision: 64 channels (12 MFMAs per accumulator) per barrier
     if (KDIP_X3_SUBS1 >= 2 && std::is_same<T, f32x3_t>::value && p.Cin % 64 == 0) return launch_cfg2<T, NTAPS, WAVES_M, WAVES_N, MT, NT, (NTAPS == 1 ? 2 : 1)>(p, st);
   }
@@ -1435,6 +1530,9 @@ static int launch_T(ConvParams& p, hipStream_t st) {
   const long mt = cdiv((long)p.B * p.H * p.W, 128);
   // (a 256x128 block with 128x64 wave tiles and a 1x4 wave layout were measured and rejected: DESIGN.md section 5,
   // tools/experiments/)
+  if constexpr (KDIP_X3_LAYOUT14 && std::is_same<T, f32x3_t>::value && NTAPS == 9) {
+    if (npad >= 128 && mt * cdiv(npad, 128) >= 512) return launch_cfg<T, NTAPS, 1, 4, 4, 1>(p, st);
+  }
   if (npad >= 128 && mt * cdiv(npad, 128) >= 512) return launch_cfg<T, NTAPS, 2, 2, 2, 2>(p, st);
   if (npad >= 64 && mt * cdiv(npad, 64) >= 512) return launch_cfg<T, NTAPS, 2, 2, 2, 1>(p, st);
   if (npad >= 128 && mt * cdiv(npad, 32) < 256) return launch_cfg<T, NTAPS, 4, 1, 1, 1>(p, st);
@@ -1465,13 +1563,24 @@ int conv_forward(hipStream_t st, DType dt, int ntaps, const void* x, long ldx, i
   p.det_slab = det ? (float*)det->slab : nullptr; p.det_slab_bytes = det ? det->slab_bytes : 0;
   p.sk_det = stt ? stt->sk_det : 0;
   p.tf_coef = stt ? stt->tf_coef : nullptr; p.tf_silu = stt ? stt->tf_silu : 0;
+  p.tf_mode = (stt && stt->tf_coef) ? stt->tf_mode : 0; p.tf_x2 = stt ? stt->tf_x2 : nullptr;
+  KDIP_REQUIRE(!p.tf_coef || p.tf_mode == 1 || (p.tf_mode == 2 && p.tf_x2 && ((uintptr_t)p.tf_x2 % 16) == 0 && !p.in_ups),
+               "conv: GroupNorm-backward staging needs the GroupNorm input tensor (same layout as the conv input)");
   KDIP_REQUIRE(!p.tf_coef || (dt == DT_F32X3 && ntaps == 9 && (long)H * W >= 128 && ((uintptr_t)p.tf_coef % 16) == 0),
                "conv: fused GroupNorm staging needs the split-precision 3x3 kernel and one image per tile");
   p.sk_ws = sk_ws; p.sk_ws_floats = sk_ws_floats; p.sk_splits = 1;
   KDIP_REQUIRE(!(p.in_ups || p.res_ups) || (H % 2 == 0 && W % 2 == 0), "conv: fused x2 upsample needs even H, W");
+  p.st_store_dz = 0;
+  p.gnb_coef = nullptr; p.gnb_dz = nullptr; p.gnb_lddz = 0; p.gnb_x = nullptr; p.gnb_ldx = 0; p.gnb_add = nullptr; p.gnb_lda = 0; p.gnb_silu = 0;
   if (stt && stt->mode) {
     p.st_mode = stt->mode; p.st_silu = stt->silu; p.st_sums = stt->sums; p.st_x = stt->x; p.st_ldx = stt->ldx;
     p.st_coef = stt->coef; p.st_mr = stt->mr;
+    p.st_store_dz = (stt->mode == 2 && stt->store_dz && dt != DT_BF16) ? 1 : 0;
+    if (stt->mode == 3) {
+      KDIP_REQUIRE(dt != DT_BF16 && ntaps == 1, "conv: the GroupNorm-backward epilogue is built for the fp32-storage 1x1 convs");
+      p.gnb_coef = stt->gnb_coef; p.gnb_dz = stt->gnb_dz; p.gnb_lddz = stt->gnb_lddz; p.gnb_x = stt->gnb_x; p.gnb_ldx = stt->gnb_ldx;
+      p.gnb_add = stt->gnb_add; p.gnb_lda = stt->gnb_lda; p.gnb_silu = stt->gnb_silu;
+    }
   }
   if (dt == DT_BF16) return ntaps == 9 ? launch_T<bf16_t, 9>(p, st) : launch_T<bf16_t, 1>(p, st);
   if (dt == DT_F32X3) return ntaps == 9 ? launch_T<f32x3_t, 9>(p, st) : launch_T<f32x3_t, 1>(p, st);

@@ -25,10 +25,28 @@ struct ConvStats {
   // split-precision 3x3 convs on maps with >= 128 pixels: the input is a GroupNorm INPUT and silu?(a*x + b), (a, b) = tf_coef [B][Cin][2]
   // (gn_coef), is applied while the patch is staged -- the activated tensor never exists in HBM (as Conv3Fuse::tf 1 does for bf16)
   const float* tf_coef = nullptr; int tf_silu = 0;
+  // tf_mode 2 (split precision, 3x3 dgrad): GroupNorm BACKWARD apply while staging -- the input is dz = dy * silu'(z) as a store_dz epilogue left it,
+  // tf_x2 [same shape and channel stride] is that GroupNorm's input, tf_coef [B][Cin][4] = (a, b, k0, k1) (gn_bwd_coef): A = a*dz - (k0 + k1*x2).
+  // The gradient w.r.t. the GroupNorm input is never written (what Conv3Fuse::tf 2 does for bf16).  nn.py:17-19 / unet.py:237-253 backward
+  int tf_mode = 1; const void* tf_x2 = nullptr;
   // deterministic modes (det.h): fused statistics reduced in a fixed order through det->slab (+ a finish kernel); sk_det:
   // sk_ws is NOT pre-zeroed and holds one slab [B*H*W][Cout] per K split (sk_ws_floats bounds the number of splits), summed in
   // split order by the finalize pass
   const DetWs* det = nullptr; int sk_det = 0;
+  // fp32 storage (f32 / split-precision modes), mode 2: the epilogue's backward-statistics sweep also WRITES dz = dy * silu'(a*x + b) over the
+  // dy it stored (the lines are still L2-hot), as conv3's st_mode-2 epilogue does for bf16: every consumer of the tensor -- the
+  // GroupNorm-backward apply pass, the gnb epilogue below, the TFM-2 staging of the next dgrad conv -- is then transcendental-free
+  int store_dz = 0;
+  // mode 3 (fp32 storage, one image per tile, Cout % tile width == 0): GroupNorm-BACKWARD APPLY folded into this conv's epilogue --
+  //   y = conv(x) + [ a*dz - (k0 + k1*gx) ] (+ add),   (a, b, k0, k1) = gnb_coef [B][Cout][4] (gn_bwd_coef), dz / gx / add [B,H,W,Cout]-shaped
+  // i.e. the ResBlock input gradient  gn_bwd_apply(conv1-dgrad output) + skip-dgrad (+ concat-skip gradient)  leaves the 1x1 skip dgrad
+  // conv directly: the skip gradient is never written to / re-read from HBM and the separate gn_bwd_apply pass disappears
+  // (guided_diffusion/unet.py:215-222,256 backward; nn.py:17-19)
+  const float* gnb_coef = nullptr;
+  const void* gnb_dz = nullptr; long gnb_lddz = 0;
+  const void* gnb_x = nullptr; long gnb_ldx = 0;
+  const void* gnb_add = nullptr; long gnb_lda = 0;
+  int gnb_silu = 0;                // gnb_dz holds dy, not dz: the epilogue applies silu'(a*gx + b) itself (the 1x1 conv is HBM-bound: the arithmetic is free there)
 };
 inline bool conv_tf_eligible(DType cdt, int ntaps, int H, int W, int Cin_pad) { return cdt == DT_F32X3 && ntaps == 9 && (long)H * W >= 128 && Cin_pad % 32 == 0; }
 // true iff conv_forward can fuse statistics for an output of this shape

@@ -273,6 +273,19 @@ int UNet::finalize() {
 // --------------------------------------------------------------------------- helpers ----
 std::atomic<int> g_gn_fold{[] { const char* e = getenv("KDIP_GN_FOLD"); return e ? (atoi(e) != 0 ? 1 : 0) : 1; }()};      // 1: conv3 computes the GroupNorm staging coefficients itself (no gn_coef / gn_merge_stats / gn_bwd_coef launches)
 void unet_debug_gn_fold(int on) { g_gn_fold.store(on ? 1 : 0); }
+// fp32-storage modes (f32 / bf16x3), read once (A/B builds and tools/ only; the workspace plan of a batch depends on them):
+//   KDIP_STORE_DZ (default 0): the backward-statistics epilogue of a dgrad conv leaves dz = dy * silu'(z) instead of dy (the second write of the
+//                              tensor measured +24 us on the 128 -> 128 @ 256^2 dgrad launches: the consumers apply silu' themselves instead)
+//   KDIP_GNB_FOLD (default 1): the ResBlock-input gradient  gn_bwd_apply(g1) + skip-dgrad + concat gradient  is produced by the 1x1 skip dgrad
+//                              conv's epilogue (ConvStats mode 3) on channel-changing blocks: no skip-gradient tensor, no gn_bwd_apply pass
+static const int g_store_dz = [] { const char* e = getenv("KDIP_STORE_DZ"); return e ? atoi(e) : 0; }();      // 0 never, 1 only where a TFM-2 dgrad conv consumes the tensor, 2 everywhere
+static const int g_gnb_fold = [] { const char* e = getenv("KDIP_GNB_FOLD"); return e ? (atoi(e) != 0 ? 1 : 0) : 1; }();
+//   KDIP_X3_TF2 (default 0): split-precision mode, the GroupNorm backward between a ResBlock's two dgrad convs is applied while the second
+//                            one stages its input (ConvStats::tf_mode 2): the gradient w.r.t. the GroupNorm input is never written.  MEASURED
+//                            NEGATIVE (round 6, profiles/r06/ab_gnb_tf2.log, interleaved twice): gn_bwd_apply 7.6 -> 4.1 ms per profiled pass, but the
+//                            two-tensor staging makes the 128 x 128-tile class 65.6 -> 78.1 ms (132 B of scratch at the 168-register budget, twice the
+//                            staging loads in front of the weight-fragment queue): step 94.8 -> 104.6 ms.  Opt-in; tests/test_x3_gpu.py runs it once.
+static const int g_x3_tf2 = [] { const char* e = getenv("KDIP_X3_TF2"); return e ? (atoi(e) != 0 ? 1 : 0) : 0; }();
 
 namespace {
 struct Ctx {
@@ -451,7 +464,9 @@ int conv_f(Ctx& c, const ConvW& w, const void* x, long ldx, int B, int H, int W,
 int conv_b(Ctx& c, const ConvW& w, const void* g, long ldg, int B, int H, int W, void* y, long ldy, const void* res,
            long ldr, int out_f32, const void* gn_x = nullptr, long gn_ldx = 0, const float* gn_coef = nullptr,
            const float* gn_mr = nullptr, int gn_silu = 0, double** sums_out = nullptr, const float* tf2_coef = nullptr,
-           const void* tf2_x2 = nullptr, int* y_is_dz = nullptr, const Conv3Fuse* fold2 = nullptr) {
+           const void* tf2_x2 = nullptr, int* y_is_dz = nullptr, const Conv3Fuse* fold2 = nullptr, const ConvStats* gnb = nullptr, int tf2_silu = 0,
+           bool dz_for_tf2 = false) {
+  // gnb (fp32 storage, 1x1): mode-3 descriptor (gnb_* fields): y = dgrad + GroupNorm-backward apply (+ addend) in the conv's epilogue
   bool dry = c.dry;
   if (sums_out) *sums_out = nullptr;
   if (y_is_dz) *y_is_dz = 0;          // 1: y holds dz = dy * silu'(z) of the GroupNorm (gn_x, gn_coef): apply its backward with silu = 0
@@ -471,8 +486,10 @@ int conv_b(Ctx& c, const ConvW& w, const void* g, long ldg, int B, int H, int W,
     RUN(conv3_forward(c.st, g, ldg, B, H, W, w.cin_pad_b, w.wb, nullptr, w.cin, y, ldy, nullptr, 0, &fu, w.cout));
     return KDIP_OK;
   }
-  if (tf2_coef) return set_error(KDIP_ERR_STATE, "internal: fused GroupNorm-backward staging requested for a conv the second-generation kernel cannot run");
+  if (tf2_coef && !(conv_tf_eligible(c.cdt(), w.ntaps, H, W, w.cin_pad_b) && !res && !out_f32))
+    return set_error(KDIP_ERR_STATE, "internal: fused GroupNorm-backward staging requested for a conv no kernel can fuse it into");
   ConvStats stt;
+  if (tf2_coef) { stt.tf_coef = tf2_coef; stt.tf_mode = 2; stt.tf_x2 = tf2_x2; stt.tf_silu = tf2_silu; }      // split precision: A = a*dz - (k0 + k1*x2) while staging (conv.hip, TFM 2)
   // (split-precision mode) gradients have no natural scale: the fp16 window of the A operand follows max |cotangent| of this VJP
   // (one reduction per VJP) -- enough for networks whose backward gains keep the gradient tensors of one VJP within +-4 decades of
   // it.  kdip_unet_x3_window(u, 1): every dgrad launch takes its own power-of-two scale from a sampled max |g| of its input instead
@@ -489,11 +506,18 @@ int conv_b(Ctx& c, const ConvW& w, const void* g, long ldg, int B, int H, int W,
     stt.sums = new_sums(c, B);
     *sums_out = stt.sums;
     if (det_ws(c, det_conv_bytes(B, H, W, w.cin), dw)) stt.det = &dw;
+    if ((g_store_dz == 2 || (g_store_dz == 1 && dz_for_tf2)) && gn_silu && y_is_dz && c.dt != DT_BF16) { stt.store_dz = 1; *y_is_dz = 1; }      // the sweep that takes the sums leaves dz behind
+  }
+  if (gnb) {
+    if (stats_ok || res || out_f32 || c.dt == DT_BF16 || w.ntaps != 1)
+      return set_error(KDIP_ERR_STATE, "internal: GroupNorm-backward epilogue requested for a conv that cannot take it");
+    stt.mode = 3; stt.gnb_coef = gnb->gnb_coef; stt.gnb_dz = gnb->gnb_dz; stt.gnb_lddz = gnb->gnb_lddz; stt.gnb_x = gnb->gnb_x; stt.gnb_ldx = gnb->gnb_ldx;
+    stt.gnb_add = gnb->gnb_add; stt.gnb_lda = gnb->gnb_lda; stt.gnb_silu = gnb->gnb_silu;
   }
   stt.sk_det = c.u->det ? 1 : 0;
   stt.x3_sat = c.u->x3_sat;
   RUN(conv_forward(c.st, c.cdt(), w.ntaps, g, ldg, B, H, W, w.cin_pad_b, w.wb, nullptr, w.cin, y, ldy, res, ldr, out_f32, 1.f, w.cout,
-                   (stt.mode || stt.x3_amax || stt.sk_det) ? &stt : nullptr, c.u->sk_ws, c.u->sk_ws_floats));
+                   (stt.mode || stt.x3_amax || stt.sk_det || stt.tf_coef) ? &stt : nullptr, c.u->sk_ws, c.u->sk_ws_floats));
   return KDIP_OK;
 }
 }  // namespace
@@ -773,18 +797,20 @@ static int res_backward(Ctx& c, Layer& L, const void* G, long ldG, void** gxp, c
   void* g3 = u->scratch.alloc(es * B * HWo * L.cout);
   double* sums2 = nullptr;     // GN2-backward sums accumulated by the dgrad epilogue when the shape allows
   int g3_dz = 0;               // g3 holds dz (the dgrad epilogue already applied silu') instead of dy
-  CK(conv_b(c, L.c2, G, ldG, B, Ho, Wo, g3, L.cout, nullptr, 0, 0, L.sv.h2, L.cout, L.sv.coef2, L.sv.mr2, 1, &sums2, nullptr, nullptr, &g3_dz));
+  const bool fbx_ok = g_x3_tf2 && c.cdt() == DT_F32X3 && conv_tf_eligible(c.cdt(), 9, Ho, Wo, L.c1.cin_pad_b) && !gn_small_eligible(c.dt, HWo, L.cout);
+  CK(conv_b(c, L.c2, G, ldG, B, Ho, Wo, g3, L.cout, nullptr, 0, 0, L.sv.h2, L.cout, L.sv.coef2, L.sv.mr2, 1, &sums2, nullptr, nullptr, &g3_dz, nullptr, nullptr, 0, fbx_ok));
   // conv1 dgrad -> grad wrt (resampled) h1.  Second-generation kernel + fused sums: the GN2 backward apply
   // (gh2 = a*dz - (k0 + k1*h2)) happens inside the dgrad conv's input staging; gh2 is never written.
   void* g1p = u->scratch.alloc(es * B * HWo * L.cin);
   double* sums1 = nullptr;
-  const bool fb = sums2 && g3_dz && use_conv3(c, L.c1, B, Ho, Wo, L.cout, L.cin, true, 0, 2);
+  const bool fbx = fbx_ok && sums2;      // split precision: GroupNorm-backward staging in conv.hip (g3 holds dz or dy: tf2_silu)
+  const bool fb = (sums2 && g3_dz && use_conv3(c, L.c1, B, Ho, Wo, L.cout, L.cin, true, 0, 2)) || fbx;
   const void* gh2 = nullptr;
   float* tf2 = nullptr;
   Conv3Fuse foldb;
   if (fb) {
     tf2 = (float*)u->scratch.alloc(sizeof(float) * B * L.cout * 4);
-    if (g_gn_fold.load()) { foldb.fold_stats = sums2; foldb.fold_coef = L.sv.coef2; foldb.fold_mr = L.sv.mr2; foldb.fold_HW = HWo; }
+    if (g_gn_fold.load() && !fbx) { foldb.fold_stats = sums2; foldb.fold_coef = L.sv.coef2; foldb.fold_mr = L.sv.mr2; foldb.fold_HW = HWo; }
     else RUN(gn_bwd_coef(c.st, L.sv.coef2, L.sv.mr2, sums2, B, HWo, L.cout, tf2));
   } else {
     void* t = u->scratch.alloc(es * B * HWo * L.cout);
@@ -793,9 +819,22 @@ static int res_backward(Ctx& c, Layer& L, const void* G, long ldG, void** gxp, c
   }
   int g1_dz = 0;
   if (L.mode == 0)
-    CK(conv_b(c, L.c1, fb ? g3 : gh2, L.cout, B, Ho, Wo, g1p, L.cin, nullptr, 0, 0, L.sv.x, L.sv.ldx, L.sv.coef1, L.sv.mr1, 1, &sums1, tf2, fb ? L.sv.h2 : nullptr, &g1_dz, &foldb));
+    CK(conv_b(c, L.c1, fb ? g3 : gh2, L.cout, B, Ho, Wo, g1p, L.cin, nullptr, 0, 0, L.sv.x, L.sv.ldx, L.sv.coef1, L.sv.mr1, 1, &sums1, tf2, fb ? L.sv.h2 : nullptr, &g1_dz, &foldb, nullptr, (fbx && !g3_dz) ? 1 : 0));
   else
-    CK(conv_b(c, L.c1, fb ? g3 : gh2, L.cout, B, Ho, Wo, g1p, L.cin, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, 0, nullptr, tf2, fb ? L.sv.h2 : nullptr, nullptr, &foldb));
+    CK(conv_b(c, L.c1, fb ? g3 : gh2, L.cout, B, Ho, Wo, g1p, L.cin, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, 0, nullptr, tf2, fb ? L.sv.h2 : nullptr, nullptr, &foldb, nullptr, (fbx && !g3_dz) ? 1 : 0));
+  // Channel-changing block on a streaming-size map, fp32 storage: the input gradient  a*dz - (k0 + k1*x) + W_skip^T G (+ concat gradient)
+  // is written by the skip dgrad conv's epilogue (ConvStats mode 3) -- no skip-gradient tensor, no gn_bwd_apply pass over 4 - 5 tensors
+  if (g_gnb_fold && L.has_skip && L.mode == 0 && c.dt != DT_BF16 && sums1 && !gn_small_eligible(c.dt, HW, L.cin) && L.cin % 128 == 0 &&
+      HW >= 128 && L.sv.ldx % 4 == 0 && lda2 % 4 == 0) {
+    float* kc = (float*)u->scratch.alloc(sizeof(float) * B * L.cin * 4);
+    RUN(gn_bwd_coef(c.st, L.sv.coef1, L.sv.mr1, sums1, B, HW, L.cin, kc));
+    void* gx = u->persist.alloc(es * B * HW * L.cin);
+    ConvStats gb;
+    gb.gnb_coef = kc; gb.gnb_dz = g1p; gb.gnb_lddz = L.cin; gb.gnb_x = L.sv.x; gb.gnb_ldx = L.sv.ldx; gb.gnb_add = add2; gb.gnb_lda = lda2; gb.gnb_silu = g1_dz ? 0 : 1;
+    CK(conv_b(c, L.skip, G, ldG, B, Ho, Wo, gx, L.cin, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, &gb));
+    *gxp = gx;
+    return KDIP_OK;
+  }
   // skip path: grad wrt (resampled) x
   const void* gS = G; long ldgS = ldG;
   if (L.has_skip) {

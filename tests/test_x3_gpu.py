@@ -165,3 +165,18 @@ def test_x3_saturation_flag():
     m2 = ku.UNetModel(dtype="bf16x3", **kw)
     m2.load_state_dict(big)
     assert m2.x3_saturated() & 2
+
+
+@pytest.mark.parametrize("env", [{"KDIP_X3_TF2": "1"}, {"KDIP_X3_TF2": "1", "KDIP_STORE_DZ": "1"}, {"KDIP_GNB_FOLD": "0", "KDIP_STORE_DZ": "2"}])
+def test_x3_optin_backward_fusions_match_reference(env):
+    """The opt-in backward fusions of the fp32-storage modes (csrc/unet.hip: KDIP_X3_TF2 = GroupNorm-backward staging inside the split-precision
+    dgrad conv -- measured slower, off by default; KDIP_STORE_DZ = dz left behind by the backward-statistics epilogue; KDIP_GNB_FOLD = 0 = the
+    round-5 path without the GroupNorm-backward epilogue of the skip dgrad conv) are read once per process: run the mid-size REFERENCE capture
+    (forward + autograd VJP + guided calls written by the imported reference, tests/test_mid_gpu.py) in a child interpreter with them set."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_mid_gpu.py"), "-x", "-q", "-m", "gpu"],
+                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, (env, r.stdout[-2000:], r.stderr[-1000:])
