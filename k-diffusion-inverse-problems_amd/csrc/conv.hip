@@ -277,6 +277,9 @@ static_assert(KDIP_SPLITK_MAX >= 1 && KDIP_SPLITK_MAX <= 64, "KDIP_SPLITK_MAX (k
 #define KDIP_X3_SUBS1 1      // split-precision 1x1 convs: 32-channel sub-chunks staged per barrier (2 = 102 KB of LDS, one block per CU: 404 vs 249 us
                              // on the 128 -> 256 @ 256x256 skip conv)
 #endif
+#ifndef KDIP_X3_B_DEPTH_SMALL
+#define KDIP_X3_B_DEPTH_SMALL 2   // ... of the narrow (128 x 64 / 128 x 32) split-precision 3x3 tiles: a stage is only 6 - 12 MFMAs per wave there
+#endif
 #ifndef KDIP_X3_SUBS1_SMALL
 #define KDIP_X3_SUBS1_SMALL 1
 #endif
@@ -995,7 +998,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
   };
   // the staging-transform instantiation trades the A-fragment prefetch (KDIP_X3_TF_APF 0: 48 registers) for the second weight stage
   constexpr bool APF = KDIP_A_PREFETCH && !(X3 && TFM && !KDIP_X3_TF_APF);
-  constexpr int BD = X3 ? ((NTAPS == 9 && (!TFM || !KDIP_X3_TF_APF || KDIP_X3_TF_BD2)) ? KDIP_X3_B_DEPTH : 1) : (MT * NT <= 2 && sizeof(T) == 2 && NTAPS == 9) ? KDIP_B_DEPTH_SMALL : KDIP_B_DEPTH;   // stages ahead
+  constexpr int BD = X3 ? ((NTAPS == 9 && (!TFM || !KDIP_X3_TF_APF || KDIP_X3_TF_BD2)) ? (MT * NT <= 2 ? KDIP_X3_B_DEPTH_SMALL : KDIP_X3_B_DEPTH) : 1) : (MT * NT <= 2 && sizeof(T) == 2 && NTAPS == 9) ? KDIP_B_DEPTH_SMALL : KDIP_B_DEPTH;   // stages ahead
   uint4 bq[BD + 1][KS][NT][NPB];
 
   // prologue: the first two B stages are requested together with the first patch, ahead of the LDS write + barrier
@@ -1412,7 +1415,10 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
     const int cls = (NTAPS == 9 ? 0 : 3) + (BN == 128 ? 0 : (BN == 64 ? 1 : 2));
     const double px = (double)p.B * p.H * p.W;
     prof_begin(st, cls, 2.0 * px * p.cin_real * p.Cout * NTAPS,
-               px * (p.cin_real + p.Cout * (p.st_mode == 3 ? (p.gnb_add ? 4 : 3) : 1)) * sizeof(T) + (double)NTAPS * p.cin_real * p.Cout * sizeof(T),
+               // every tensor the launch must read or write once: input, output, weights, + the residual, + the GroupNorm input of the backward-statistics
+               // sweep (mode 2), + dz / GroupNorm input / addend of the GroupNorm-backward epilogue (mode 3), + the second staged tensor (TFM 2)
+               px * (p.cin_real * (p.tf_mode == 2 ? 2 : 1) + p.Cout * (1 + (p.res ? 1 : 0) + (p.st_mode == 2 ? 1 : 0) + (p.st_mode == 3 ? (p.gnb_add ? 3 : 2) : 0))) * sizeof(T) +
+                   (double)NTAPS * p.cin_real * p.Cout * sizeof(T),
                p.st_mode == 3 ? "conv_gnb" : "conv", p.B, p.H, p.cin_real, p.Cout);
   }
   if (lds > 48 * 1024) {
@@ -1535,6 +1541,8 @@ static int launch_T(ConvParams& p, hipStream_t st) {
   }
   if (npad >= 128 && mt * cdiv(npad, 128) >= 512) return launch_cfg<T, NTAPS, 2, 2, 2, 2>(p, st);
   if (npad >= 64 && mt * cdiv(npad, 64) >= 512) return launch_cfg<T, NTAPS, 2, 2, 2, 1>(p, st);
+  // (split precision, 8 x 8 maps at 8 images -- 4 m-tiles: the 128 x 64 tile + 16 K splits measures 27.1 vs 32.9 us on 512 -> 512, tools/r06_smallmap_scan.sh)
+  if (std::is_same<T, f32x3_t>::value && NTAPS == 9 && npad >= 128 && mt <= 4 && p.sk_ws) return launch_cfg<T, NTAPS, 2, 2, 2, 1>(p, st);
   if (npad >= 128 && mt * cdiv(npad, 32) < 256) return launch_cfg<T, NTAPS, 4, 1, 1, 1>(p, st);
   if (npad >= 64 && mt * cdiv(npad, 32) >= 512) return launch_cfg<T, NTAPS, 4, 1, 1, 1>(p, st);
   if (npad >= 128) return launch_cfg<T, NTAPS, 2, 2, 2, 1>(p, st);

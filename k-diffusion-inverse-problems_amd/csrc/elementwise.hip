@@ -291,6 +291,74 @@ int nhwc_T_to_nchw_f32(hipStream_t st, DType dt, const void* x, long ld, int B, 
 }
 
 
+// ---- 3x3 convs with a handful of input or output channels as 1x1 convs (fp32-storage modes; round 6) --------------------------------
+// The image conv (3 -> C), the output head (C -> 6) and their input-gradients are 3x3 convs whose K or N the implicit-GEMM kernel pads to
+// 32: 10x / 5x the MFMA work of the useful products, 2.5 % of the MFMA instructions of a guided call.  Both are 1x1 convs in disguise:
+//   few INPUT channels (guided_diffusion/unet.py:484 forward, :614-618 backward): fold the taps into K.  im2col3_nchw writes
+//       X1[b, y, x, t*C + c] = scale * x[b, c, y + t/3 - 1, x + t%3 - 1]   (zero outside the image, zero in the padding channels)
+//     straight from the NCHW fp32 tensor the C ABI hands over (it replaces nchw_to_nhwc), and the conv is a 1x1 with K = 9 C (27 -> 32, 54 -> 64).
+//   few OUTPUT channels (:614-618 forward, :484 backward): fold the taps into N.  A 1x1 conv with N = 9 Co (54 -> 64, 27 -> 32) leaves the per-tap
+//     partial products P[b, y, x, t*Co + co]; tap_gather_nchw adds the nine shifted taps and the bias and writes the NCHW fp32 result
+//       out[b, co, y, x] = bias[co] + sum_t P[b, y + t/3 - 1, x + t%3 - 1, t*Co + co]
+//     (it replaces nhwc_to_nchw_f32).
+__global__ void im2col3_nchw_kernel(const float* __restrict__ x, int B, int C, int H, int W, float scale, float* __restrict__ y, long ld) {
+  const int nv = (int)(ld / 4);                       // 16-byte vectors per pixel row (ld = padded 9 C)
+  const long HW = (long)H * W, nvec = (long)B * HW * nv;
+  for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < nvec; j += (long)gridDim.x * blockDim.x) {
+    const long i = j / nv; const int v = (int)(j - i * nv);
+    const long b = i / HW; const int p = (int)(i - b * HW), py = p / W, px = p - py * W;
+    float f[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = v * 4 + e, t = k / C, c = k - t * C;
+      const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
+      f[e] = (t < 9 && yy >= 0 && yy < H && xx >= 0 && xx < W) ? x[(b * C + c) * HW + (long)yy * W + xx] * scale : 0.f;
+    }
+    *(float4*)(y + i * ld + (long)v * 4) = make_float4(f[0], f[1], f[2], f[3]);
+  }
+}
+int im2col3_nchw(hipStream_t st, const float* x, int B, int C, int H, int W, float scale, float* y, long ld) {
+  KDIP_REQUIRE(ld % 4 == 0 && ld >= 9 * C && ((uintptr_t)y % 16) == 0, "im2col3: bad row stride %ld for %d channels", ld, C);
+  hipLaunchKernelGGL(im2col3_nchw_kernel, dim3(ew_grid((long)B * H * W * (ld / 4))), dim3(256), 0, st, x, B, C, H, W, scale, y, ld);
+  KDIP_LAUNCH_CHECK();
+  return KDIP_OK;
+}
+template <int CO>
+__global__ void tap_gather_nchw_kernel(const float* __restrict__ P, long ld, int B, int H, int W, const float* __restrict__ bias, float* __restrict__ out) {
+  const long HW = (long)H * W, n = (long)B * HW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / HW; const int p = (int)(i - b * HW), py = p / W, px = p - py * W;
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = bias ? bias[c] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {                      // fixed tap order: the result is run-to-run reproducible
+      const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+        const float* q = P + (b * HW + (long)yy * W + xx) * ld + t * CO;
+        if (CO % 2 == 0) {                             // t * CO floats is 8-byte aligned
+#pragma unroll
+          for (int c = 0; c < CO; c += 2) { const float2 v = *(const float2*)(q + c); acc[c] += v.x; acc[c + 1] += v.y; }
+        } else {
+#pragma unroll
+          for (int c = 0; c < CO; ++c) acc[c] += q[c];
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CO; ++c) out[(b * CO + c) * HW + p] = acc[c];
+  }
+}
+int tap_gather_nchw(hipStream_t st, const float* P, long ld, int B, int Co, int H, int W, const float* bias, float* out) {
+  KDIP_REQUIRE(ld >= 9 * Co && ld % 2 == 0 && ((uintptr_t)P % 8) == 0, "tap_gather: bad row stride %ld for %d channels", ld, Co);
+  const dim3 g(ew_grid((long)B * H * W)), bl(256);
+  if (Co == 3) hipLaunchKernelGGL(tap_gather_nchw_kernel<3>, g, bl, 0, st, P, ld, B, H, W, bias, out);
+  else if (Co == 6) hipLaunchKernelGGL(tap_gather_nchw_kernel<6>, g, bl, 0, st, P, ld, B, H, W, bias, out);
+  else return set_error(KDIP_ERR_UNSUPPORTED, "tap_gather: %d output channels (3 or 6)", Co);
+  KDIP_LAUNCH_CHECK();
+  return KDIP_OK;
+}
+
 // ------------------------------------------------------------------ LPIPS (VGG) helpers ----
 // The perceptual metric of the caller harness (sample_condition_openai.py:46,161: lpips.LPIPS(net='vgg')) runs its 13 VGG convs
 // through conv_forward; these kernels are the glue on fp32 NCHW planes: ReLU (+ 2x2 max pool) and the per-layer distance.

@@ -173,6 +173,9 @@ int T_to_f32(hipStream_t st, DType dt, const void* x, long n, float* y);
 // NCHW fp32 [B,C,H,W] * scale -> NHWC T [B,H,W,ld] (channels >= C zero-filled up to Cpad)
 int nchw_to_nhwc(hipStream_t st, DType dt, const float* x, int B, int C, int H, int W, float scale, void* y, long ld, int Cpad);
 int nhwc_to_nchw_f32(hipStream_t st, const float* x, long ld, int B, int C, int H, int W, float* y);
+// few-channel 3x3 convs as 1x1 convs (elementwise.hip): taps folded into K (im2col of the NCHW input) or into N (per-tap partial products + gather)
+int im2col3_nchw(hipStream_t st, const float* x, int B, int C, int H, int W, float scale, float* y, long ld);
+int tap_gather_nchw(hipStream_t st, const float* P, long ld, int B, int Co, int H, int W, const float* bias, float* out);
 int nhwc_T_to_nchw_f32(hipStream_t st, DType dt, const void* x, long ld, int B, int C, int H, int W, float* y);
 
 }  // namespace kdip

@@ -124,10 +124,12 @@ __global__ void gn_stats_kernel(const T* __restrict__ x, long ldx, long HW, int 
 }
 
 static long pick_chunk(long HW, int B) {
-  // aim for >= ~1024 blocks, at least 256 pixels per block
+  // aim for >= ~1024 blocks, at least 32 pixels per block.  (The floor was 256 pixels until round 6: on the 32^2 / 64^2 maps that left 32 - 128
+  // blocks, each walking its 256 pixels with one or two loads in flight per thread -- 56 us for gn_bwd_stats at 8 x 64^2 x 256 and 112 us for
+  // gn_stats at 8 x 32^2 x 768, 220 - 1 200 GB/s.)  unet.hip's det_gn_bytes sizes the deterministic slab with the same rule.
   long want = (1024 + B - 1) / B;
   long chunk = (HW + want - 1) / want;
-  if (chunk < 256) chunk = 256;
+  if (chunk < 32) chunk = 32;
   return chunk;
 }
 

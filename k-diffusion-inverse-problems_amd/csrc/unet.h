@@ -73,6 +73,12 @@ struct UNet {
   LinW emb_all;                     // all ResBlock emb_layers.1 stacked: one launch per forward
   int emb_total = 0;
   GnW out_norm; ConvW out_conv; ConvW cov_conv; bool has_cov = false;
+  // fp32-storage modes: the few-channel 3x3 convs restated as 1x1 convs (elementwise.hip: im2col3_nchw / tap_gather_nchw; built by finalize()).
+  //   in_k1  image conv forward    : K = 9 x in_channels (taps folded into K),   N = first block width
+  //   in_n1  image conv dgrad      : K = first block width,                     N = 9 x in_channels (taps folded into N)   -> wb
+  //   out_n1 output head forward   : K = final_ch,                              N = 9 x out_channels                      -> wf
+  //   out_k1 output head dgrad     : K = 9 x out_channels,                      N = final_ch                               -> wb
+  ConvW in_k1, in_n1, out_n1, out_k1; bool tapfold = false;
   std::map<std::string, std::vector<float>> raw;      // host fp32 parameters by reference state_dict name
   std::map<std::string, std::vector<long>> raw_shape;
   bool finalized = false;

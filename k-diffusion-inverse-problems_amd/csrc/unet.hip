@@ -32,6 +32,11 @@ namespace kdip {
 
 static inline int pad32(int c) { return (c + 31) / 32 * 32; }
 
+// fp32-storage modes, read once (A/B builds and tools/ only):
+//   KDIP_TAPFOLD (default 1): the 3- / 6-channel 3x3 convs (image conv, output head and their input-gradients) run as 1x1 convs with the
+//                             taps folded into K or N (unet.h: in_k1 / in_n1 / out_n1 / out_k1) instead of padding K or N to 32
+static const int g_tapfold = [] { const char* e = getenv("KDIP_TAPFOLD"); return e ? (atoi(e) != 0 ? 1 : 0) : 1; }();
+
 // ------------------------------------------------------------------ tiny fp32 linear ----
 // y[b][o] = bias[o] + sum_i act(x[b][i]) * w[o][i]; one wavefront per output (emb MLPs,
 // guided_diffusion/unet.py:199-205,472-477: M = batch, latency-bound).
@@ -258,6 +263,47 @@ int UNet::finalize() {
     mkconv(cov_conv, "out_cov", final_ch, 6, 1);   // OpenAIDenoiserV2.out_cov (k_diffusion/external.py:141)
     has_cov = true;
   }
+  if (!rc && g_tapfold && dt != DT_BF16 && 9 * cfg.in_channels <= 32 && 9 * cfg.out_channels <= 64) {
+    // logical 3x3 conv Wl[Co][Ci][9] -> (a) taps in K: 1x1 weights [Co][9 Ci] (k = t*Ci + c);  (b) taps in N: 1x1 weights [Np][Ci], row n = t*Co + co
+    // (rows >= 9 Co zero: N padded so that the 16-byte-vector epilogue applies).  dgrad: Wl[ci][co][t] = W[co][ci][8 - t] (flipped, transposed).
+    auto logical = [&](const float* w, int cout, int cin, bool dgrad) {
+      const int Co = dgrad ? cin : cout, Ci = dgrad ? cout : cin;
+      std::vector<float> l((size_t)Co * Ci * 9);
+      for (int o = 0; o < Co; ++o) for (int i = 0; i < Ci; ++i) for (int t = 0; t < 9; ++t)
+        l[((size_t)o * Ci + i) * 9 + t] = dgrad ? w[((size_t)i * cin + o) * 9 + (8 - t)] : w[((size_t)o * cin + i) * 9 + t];
+      return l;
+    };
+    auto pack1 = [&](const std::vector<float>& w1, int N, int K) -> void* {      // 1x1 conv weights [N][K] -> packed fragments (K padded to 32)
+      std::vector<char> buf(packed_weight_bytes(cdt, 1, pad32(K), N));
+      pack_conv_weight(cdt, w1.data(), N, K, 1, 0, pad32(K), buf.data());
+      return upload(buf.data(), buf.size());
+    };
+    auto taps_in_k = [&](const std::vector<float>& l, int Co, int Ci) {
+      std::vector<float> w1((size_t)Co * 9 * Ci);
+      for (int o = 0; o < Co; ++o) for (int i = 0; i < Ci; ++i) for (int t = 0; t < 9; ++t) w1[(size_t)o * 9 * Ci + t * Ci + i] = l[((size_t)o * Ci + i) * 9 + t];
+      return pack1(w1, Co, 9 * Ci);
+    };
+    auto taps_in_n = [&](const std::vector<float>& l, int Co, int Ci, int Np) {
+      std::vector<float> w1((size_t)Np * Ci, 0.f);
+      for (int o = 0; o < Co; ++o) for (int i = 0; i < Ci; ++i) for (int t = 0; t < 9; ++t) w1[((size_t)t * Co + o) * Ci + i] = l[((size_t)o * Ci + i) * 9 + t];
+      return pack1(w1, Np, Ci);
+    };
+    const int ic = cfg.in_channels, oc = cfg.out_channels, c0 = inp[0][0].cout, cf = final_ch;
+    const float* wi = need("input_blocks.0.0.weight", (long)c0 * ic * 9);
+    const float* wo = need("out.2.weight", (long)oc * cf * 9);
+    if (wi && wo) {
+      const int nin = pad32(9 * ic), nout = pad32(9 * oc);
+      in_k1.ntaps = 1; in_k1.cin = 9 * ic; in_k1.cin_pad = pad32(9 * ic); in_k1.cout = c0; in_k1.bias = inp[0][0].conv.bias;
+      in_k1.wf = taps_in_k(logical(wi, c0, ic, false), c0, ic);
+      in_n1.ntaps = 1; in_n1.cin = nin; in_n1.cout = c0; in_n1.cin_pad_b = pad32(c0);                       // conv_b: K = cin_pad_b, N = cin
+      in_n1.wb = taps_in_n(logical(wi, c0, ic, true), ic, c0, nin);
+      out_n1.ntaps = 1; out_n1.cin = cf; out_n1.cin_pad = pad32(cf); out_n1.cout = nout; out_n1.bias = nullptr;   // (the bias is added by tap_gather_nchw)
+      out_n1.wf = taps_in_n(logical(wo, oc, cf, false), oc, cf, nout);
+      out_k1.ntaps = 1; out_k1.cin = cf; out_k1.cout = 9 * oc; out_k1.cin_pad_b = pad32(9 * oc);
+      out_k1.wb = taps_in_k(logical(wo, oc, cf, true), cf, oc);
+      tapfold = true;
+    }
+  }
   if (!rc && cdt == DT_F32X3) {
     const unsigned zero = 0;
     x3_amax = (unsigned*)upload(&zero, sizeof(zero));
@@ -302,9 +348,9 @@ bool det_ws(Ctx& c, size_t slab_bytes, DetWs& w) {
   w.slab = c.u->scratch.alloc(slab_bytes); w.slab_bytes = slab_bytes;
   return true;
 }
-size_t det_gn_bytes(int B, long HW) {      // gn_stats / gn_bwd_stats: [B][chunks][64] doubles, chunks <= max(1024 / B, HW / 256) + 1
+size_t det_gn_bytes(int B, long HW) {      // gn_stats / gn_bwd_stats: [B][chunks][64] doubles, chunks <= min(ceil(1024 / B), HW / 32 + 1) (norm.hip, pick_chunk)
   long chunks = (1024 + B - 1) / B;
-  if (HW / 256 + 1 < chunks) chunks = HW / 256 + 1;
+  if (HW / 32 + 1 < chunks) chunks = HW / 32 + 1;
   return (size_t)B * (chunks + 1) * 64 * sizeof(double);
 }
 size_t det_conv_bytes(int B, int H, int W, int Cout) {      // fused conv statistics: [tiles of 128 pixels][Cout / 4 vectors][2] floats
@@ -711,7 +757,8 @@ int UNet::forward_impl(hipStream_t st, const float* x_nchw, const float* t, int 
   RUN(linear_f32(st, emb, emb_all, B, 0, film_all));       // every ResBlock's Linear(SiLU(emb)) in one launch
   // input: NCHW fp32 * c_in -> NHWC T, channels padded to 32
   void* xin = persist.alloc(es * (size_t)B * H * W * 32);
-  RUN(nchw_to_nhwc(st, dt, x_nchw, B, cfg.in_channels, H, W, in_scale, xin, 32, 32));
+  if (tapfold) RUN(im2col3_nchw(st, x_nchw, B, cfg.in_channels, H, W, in_scale, (float*)xin, 32));      // [B,H,W,32]: 9 taps x 3 channels (+ 5 zeros): the image conv is a 1x1 conv over it
+  else RUN(nchw_to_nhwc(st, dt, x_nchw, B, cfg.in_channels, H, W, in_scale, xin, 32, 32));
   hs_ptr.clear(); hs_C.clear(); cat_ptr.clear();
   std::vector<int> hs_H;
   const void* h = nullptr; long ldh = 0; int Ch = 0;
@@ -726,7 +773,7 @@ int UNet::forward_impl(hipStream_t st, const float* x_nchw, const float* t, int 
         scratch.reset();
         o = d ? d : persist.alloc(es * (size_t)B * H * W * L.cout);
         L.sv.B = B; L.sv.H = H; L.sv.W = W;
-        CK(conv_f(c, L.conv, xin, 32, B, H, W, o, d ? ldd : L.cout, nullptr, 0, 0, true));
+        CK(conv_f(c, tapfold ? in_k1 : L.conv, xin, 32, B, H, W, o, d ? ldd : L.cout, nullptr, 0, 0, true));
       } else if (L.kind == 1) {
         CK(res_forward(c, L, h, ldh, B, H, W, film_all, &o, d, ldd));
       } else {
@@ -767,9 +814,15 @@ int UNet::forward_impl(hipStream_t st, const float* x_nchw, const float* t, int 
   const long HW = (long)H * W;
   void* hn = scratch.alloc(es * B * HW * final_ch);
   CK(gn_forward(c, h, ldh, B, HW, out_norm, nullptr, 1, hn, final_ch, &out_coef, &out_mr));
+  if (tapfold) {      // per-tap partial products [B,H,W,9 x out_channels (+ padding)] from a 1x1 conv, then the nine shifted taps + bias -> NCHW
+    float* pt = (float*)scratch.alloc(sizeof(float) * B * HW * out_n1.cout);
+    CK(conv_f(c, out_n1, hn, final_ch, B, H, W, pt, out_n1.cout, nullptr, 0, 0));
+    RUN(tap_gather_nchw(st, pt, out_n1.cout, B, cfg.out_channels, H, W, out_conv.bias, out_nchw));
+  } else {
   float* o32 = (float*)scratch.alloc(sizeof(float) * B * HW * 32);
   CK(conv_f(c, out_conv, hn, final_ch, B, H, W, o32, 32, nullptr, 0, 1));
   RUN(nhwc_to_nchw_f32(st, o32, 32, B, cfg.out_channels, H, W, out_nchw));
+  }
   if (cov_nchw) {
     KDIP_REQUIRE(has_cov, "out_cov weights were not loaded");
     float* c32 = (float*)scratch.alloc(sizeof(float) * B * HW * 32);
@@ -930,13 +983,15 @@ int UNet::vjp_impl(hipStream_t st, const float* cot_nchw, float* gx_nchw) {
   if (!dry && zeros.cap > zeros_fwd_end)
     KDIP_HIP_CHECK(hipMemsetAsync(zeros.base + zeros_fwd_end, 0, zeros.cap - zeros_fwd_end, st));
   // cotangent NCHW fp32 [B,out_ch,H,W] -> NHWC T padded to 32 channels
-  void* cot = persist.alloc(es * B * HW0 * 32);
-  RUN(nchw_to_nhwc(st, dt, cot_nchw, B, cfg.out_channels, H0, W0, 1.f, cot, 32, 32));
+  const int cotw = tapfold ? out_k1.cin_pad_b : 32;
+  void* cot = persist.alloc(es * B * HW0 * cotw);
+  if (tapfold) RUN(im2col3_nchw(st, cot_nchw, B, cfg.out_channels, H0, W0, 1.f, (float*)cot, cotw));      // taps folded into K: the head's dgrad is a 1x1 conv
+  else RUN(nchw_to_nhwc(st, dt, cot_nchw, B, cfg.out_channels, H0, W0, 1.f, cot, 32, 32));
   if (x3_amax && !x3_window_per_launch) RUN(amax_bits(st, cot_nchw, (long)B * cfg.out_channels * HW0, x3_amax));
   void* ghn = scratch.alloc(es * B * HW0 * final_ch);
   double* sumsh = nullptr;
   int gh_dz = 0;
-  CK(conv_b(c, out_conv, cot, 32, B, H0, W0, ghn, final_ch, nullptr, 0, 0, final_h, final_ch, out_coef, out_mr, 1, &sumsh, nullptr, nullptr, &gh_dz));
+  CK(conv_b(c, tapfold ? out_k1 : out_conv, cot, cotw, B, H0, W0, ghn, final_ch, nullptr, 0, 0, final_h, final_ch, out_coef, out_mr, 1, &sumsh, nullptr, nullptr, &gh_dz));
   void* G = persist.alloc(es * B * HW0 * final_ch);
   CK(gn_backward(c, final_h, final_ch, ghn, final_ch, out_coef, out_mr, B, HW0, final_ch, gh_dz ? 0 : 1, nullptr, 0, G, final_ch, sumsh));
   const void* g = G; long ldg = final_ch;
@@ -976,9 +1031,15 @@ int UNet::vjp_impl(hipStream_t st, const float* cot_nchw, float* gx_nchw) {
     Layer& L0 = inp[0][0];
     const long np = (long)B * HW0;
     scratch.reset();
+    if (tapfold) {      // taps folded into N: per-tap partial input-gradients from a 1x1 conv, gathered into the NCHW gradient
+      float* pt = (float*)scratch.alloc(sizeof(float) * np * in_n1.cin);
+      CK(conv_b(c, in_n1, g, ldg, B, H0, W0, pt, in_n1.cin, nullptr, 0, 0));
+      RUN(tap_gather_nchw(st, pt, in_n1.cin, B, cfg.in_channels, H0, W0, nullptr, gx_nchw));
+    } else {
     float* gx32 = (float*)scratch.alloc(sizeof(float) * np * 32);
     CK(conv_b(c, L0.conv, g, ldg, B, H0, W0, gx32, 32, nullptr, 0, 1));
     RUN(nhwc_to_nchw_f32(st, gx32, 32, B, cfg.in_channels, H0, W0, gx_nchw));
+    }
   }
   return KDIP_OK;
 }

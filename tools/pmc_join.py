@@ -46,12 +46,13 @@ for key, c in shapes.items():
     e["mean_launch_us_under_pmc"] = sum(durs) / len(durs)
     if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
         e["FETCH_SIZE_KiB_raw"] = m["FETCH_SIZE"]; e["WRITE_SIZE_KiB_raw"] = m["WRITE_SIZE"]
-        # gfx950: FETCH_SIZE = read requests x 64 B; a wide coalesced read (>= 128 contiguous bytes per pixel row) issues 128-byte requests
-        # that are tallied at 64 B -> x 2 (MI355X_MICROARCH.md, HBM).  The split-precision 128 x 128-tile 3x3 kernel stages 16 channels
-        # = 64 contiguous bytes per pixel per chunk: its requests ARE 64 bytes, no doubling.
-        narrow = DT != "bf16" and "|f32x3_t,9,2,2,2,2," in key
-        e["fetch_bytes_per_request_assumed"] = 64 if narrow else 128
-        e["hbm_bytes_per_launch"] = m["FETCH_SIZE"] * 1024 * (1 if narrow else 2) + m["WRITE_SIZE"] * 1024
+        # gfx950: FETCH_SIZE = (128-byte line fetches of the L2) x 64 B -- HALF the bytes -- for EVERY access pattern of this library, including the
+        # 64-byte-per-pixel staging of the split-precision 128 x 128 tile (the other half of the line is used by the next 16-channel chunk and
+        # hits in L2).  Calibrated in round 6 on known byte counts past the Infinity Cache (tools/calib/, profiles/r06/fetch_calibration.txt):
+        # wide 16 B / lane reads 2.000, the 64 B-per-512 B-row staging pattern 1.996, 256 B rows 2.000; WRITE_SIZE 1.000.  (Rounds 4 - 5 assumed 64-byte
+        # requests for that kernel and under-reported its reads by 2 x.)
+        e["fetch_bytes_per_counted_64B"] = 128
+        e["hbm_bytes_per_launch"] = m["FETCH_SIZE"] * 1024 * 2 + m["WRITE_SIZE"] * 1024
         e["traffic_over_algorithmic"] = e["hbm_bytes_per_launch"] / e["algorithmic_bytes"]
     if "SQ_VALU_MFMA_BUSY_CYCLES" in m and "GRBM_GUI_ACTIVE" in m:
         # SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs
