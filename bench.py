@@ -502,7 +502,7 @@ def main():
         # HBM traffic of this (kernel, fusion mode, layer shape): rocprofv3 --pmc passes over the same in-network launches
         # (tools/pmc_innetwork.sh -> profiles/r04_pmc_innetwork.json; FETCH_SIZE x 2 + WRITE_SIZE per MI355X_MICROARCH.md)
         traffic, traffic_source, pmc_extra = None, None, {}
-        cands = ["r05_pmc_innetwork_" + args.dtype] + (["r05_pmc_innetwork", "r04_pmc_innetwork", "r03_pmc_innetwork", "r02_pmc_innetwork"] if args.dtype == "bf16" else [])
+        cands = ["r06_pmc_innetwork_" + args.dtype, "r05_pmc_innetwork_" + args.dtype] + (["r06_pmc_innetwork", "r05_pmc_innetwork", "r04_pmc_innetwork", "r03_pmc_innetwork", "r02_pmc_innetwork"] if args.dtype == "bf16" else [])
         pmc = next((f for f in (os.path.join(ROOT, "profiles", t + ".json") for t in cands) if os.path.exists(f)), "")
         if pmc:
             try:
@@ -514,9 +514,11 @@ def main():
                     traffic = e.get("hbm_bytes_per_launch")
                     traffic_source = ("profiles/" + os.path.basename(pmc) + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the in-network launches "
                                       "of this kernel + fusion mode + layer shape (tools/pmc_innetwork.sh on one guided Heun step of this workload); "
-                                      "not re-measured in this run")
+                                      "not re-measured in this run.  bytes = FETCH_SIZE x 2 + WRITE_SIZE x 1: factors CALIBRATED on known byte counts in this "
+                                      "kernel's own access patterns (profiles/r06/fetch_calibration.txt: 2.000 / 1.996 / 2.000 for reads, 1.000 for writes)")
                     pmc_extra = {k: e[k] for k in ("traffic_over_algorithmic", "mfma_busy_frac", "shader_clock_ghz", "lds_bank_conflict_frac_of_lds_active",
-                                                   "l2_hit_rate") if k in e}
+                                                   "l2_hit_rate", "FETCH_SIZE_KiB_raw", "WRITE_SIZE_KiB_raw", "algorithmic_bytes") if k in e}
+                    pmc_extra["fetch_size_factor"] = 2.0; pmc_extra["write_size_factor"] = 1.0
             except Exception:
                 traffic = None
         fusion = {"conv3": "plain", "conv3_gnf": "GroupNorm+SiLU fused into the input staging", "conv3_gnb": "GroupNorm backward fused into the input staging"}

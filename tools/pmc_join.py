@@ -33,6 +33,7 @@ for d in "abcde":
         for r in rows:
             shapes[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
         shapes[key]["_dur_us_" + d].append((float(rows[0]["End_Timestamp"]) - float(rows[0]["Start_Timestamp"])) * 1e-3)
+        shapes[key]["_alg_mb"].append(float(rec["mbytes"])); shapes[key]["_alg_gflop"].append(float(rec["gflop"]))
         shapes[key]["_vgpr"].append(float(rows[0]["VGPR_Count"]) + float(rows[0].get("Accum_VGPR_Count", 0) or 0))
 out = {"source": "rocprofv3 --kernel-trace --pmc <group> -- python tools/pmc_step.py (tools/pmc_innetwork.sh), one pass per counter group; "
                  "launch i of the library's profile dump = dispatch i of the conv3 kernels", "shapes": {}}
@@ -40,8 +41,9 @@ for key, c in shapes.items():
     m = {k: sum(v) / len(v) for k, v in c.items()}
     rec = meta[key]
     B, H, Cin, Cout = int(rec["d0"]), int(rec["d1"]), int(rec["d2"]), int(rec["d3"])
-    e = {"launches_per_pass": len(c.get("FETCH_SIZE", c.get("GRBM_GUI_ACTIVE", []))), "algorithmic_gflop": float(rec["gflop"]),
-         "algorithmic_bytes": float(rec["mbytes"]) * 1e6}
+    # (launches of one key differ in what they must move -- residual or not, backward-statistics input or not: mean over the launches)
+    e = {"launches_per_pass": len(c.get("FETCH_SIZE", c.get("GRBM_GUI_ACTIVE", []))), "algorithmic_gflop": m["_alg_gflop"],
+         "algorithmic_bytes": m["_alg_mb"] * 1e6}
     durs = [m[k] for k in m if k.startswith("_dur_us_")]
     e["mean_launch_us_under_pmc"] = sum(durs) / len(durs)
     if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
