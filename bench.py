@@ -270,6 +270,7 @@ def main():
     ap.add_argument("--no-large-batch", action="store_true", help="skip the extra throughput leg at batch 128 (N = 1 only)")
     ap.add_argument("--streams", type=int, default=2, help="part-batches per GPU, each on its own HIP stream + host thread")
     ap.add_argument("--stagger-ms", type=float, default=0.0, help="start part-batch k of a GPU k x this many milliseconds after part 0 (phase offset between the streams; inside the timed region)")
+    ap.add_argument("--stream-prio", action="store_true", help="give every second part-batch stream the higher HIP stream priority (scheduling experiment)")
     ap.add_argument("--cu-split", action="store_true", help="give each part-batch stream its own share of the compute units (CU-masked HIP streams)")
     ap.add_argument("--dtype", choices=("bf16", "f32", "bf16x3"), default="bf16x3",
                     help="UNet arithmetic: bf16x3 (default) = fp32 storage + split-precision convs, the fast mode that meets north_star's 1e-3 dB against the "
@@ -342,7 +343,8 @@ def main():
                 L.check(lib.kdip_stream_create_cu_mask(dev.index if hasattr(dev, "index") and dev.index is not None else torch.cuda.current_device(), words, 8, C.byref(hs)))
                 stream = torch.cuda.ExternalStream(hs.value, device=dev)
             else:
-                stream = torch.cuda.Stream(device=dev) if nstreams > 1 else torch.cuda.current_stream()
+                # --stream-prio: odd part-batch streams get the higher HIP stream priority (experiment: does an asymmetric pair overlap better?)
+                stream = (torch.cuda.Stream(device=dev, priority=(-1 if (args.stream_prio and k % 2) else 0)) if nstreams > 1 else torch.cuda.current_stream())
             parts.append(dict(den=den, x0=x0, noise=noise, stream=stream, B=Bk))
         torch.cuda.synchronize()
         return parts
