@@ -272,7 +272,7 @@ def main():
     ap.add_argument("--stagger-ms", type=float, default=0.0, help="start part-batch k of a GPU k x this many milliseconds after part 0 (phase offset between the streams; inside the timed region)")
     ap.add_argument("--stream-prio", action="store_true", help="give every second part-batch stream the higher HIP stream priority (scheduling experiment)")
     ap.add_argument("--cu-split", action="store_true", help="give each part-batch stream its own share of the compute units (CU-masked HIP streams)")
-    ap.add_argument("--dtype", choices=("bf16", "f32", "bf16x3"), default="bf16x3",
+    ap.add_argument("--dtype", choices=("bf16", "f32", "bf16x3", "f16x3"), default="bf16x3",
                     help="UNet arithmetic: bf16x3 (default) = fp32 storage + split-precision convs, the fast mode that meets north_star's 1e-3 dB against the "
                          "reference's fp32 arithmetic; f32 = exact-f32 MFMA; bf16 = the throughput mode (narrower than the reference: reported beside the headline, never as it)")
     ap.add_argument("--no-graph-leg", action="store_true", help="skip the extra leg that replays the guided calls from hipGraphs (N = 1 only)")
@@ -423,6 +423,9 @@ def main():
                                "torch_peak_allocated": round(torch.cuda.max_memory_allocated() / 1e9, 3)}
     except Exception as e:
         out["workspace_gb"] = {"error": repr(e)[:120]}
+    if args.dtype == "f16x3":       # fp16-headed split: calls of the timed region that had to be redone bf16-headed because an operand left the fp16 window (UNetModel.guarded)
+        out["x3_fallbacks"] = sum(unet_of(pt["den"]).x3_fallbacks for pt in parts)
+        out["x3_degraded_fallbacks"] = sum(unet_of(pt["den"]).x3_degraded for pt in parts)
     if args.dtype == "bf16x3":      # every conv product of the timed region carried its full split precision (no operand left the fp16 window of the tail planes)
         sat = 0
         for pt in parts:
@@ -526,7 +529,7 @@ def main():
         fusion = {"conv3": "plain", "conv3_gnf": "GroupNorm+SiLU fused into the input staging", "conv3_gnb": "GroupNorm backward fused into the input staging"}
         tagparts = key[1].split("_")
         base = "_".join(tagparts[:2]) if len(tagparts) > 1 and tagparts[1] in ("gnf", "gnb") else tagparts[0]
-        desc = fusion.get(base, "first-generation kernel (conv.hip)" + (": split precision, 1 v_mfma_f32_32x32x16_bf16 + 2 v_mfma_f32_32x32x16_f16 per product" if args.dtype == "bf16x3" else "")) + ("; GroupNorm forward sums of the output in the epilogue" if "s1" in tagparts else "") + \
+        desc = fusion.get(base, "first-generation kernel (conv.hip)" + (": split precision, 1 v_mfma_f32_32x32x16_bf16 + 2 v_mfma_f32_32x32x16_f16 per product" if args.dtype == "bf16x3" else (": fp16-headed split precision, 3 v_mfma_f32_32x32x16_f16 per product (every call polled, redone bf16-headed outside the fp16 window)" if args.dtype == "f16x3" else ""))) + ("; GroupNorm forward sums of the output in the epilogue" if "s1" in tagparts else "") + \
             ("; GroupNorm backward sums of the output in the epilogue" if "s2" in tagparts else "") + ("; residual add" if "res" in tagparts else "")
         names = [lib.kdip_profile_class_name(j).decode() for j in range(n)]
         k = max((j for j in range(n) if names[j].startswith("conv")), key=lambda j: ms[j])
@@ -537,8 +540,8 @@ def main():
             "frac": round(tflops / BF16_MFMA_PEAK_TFLOPS, 4),
             # `achieved` counts ALGORITHMIC flops (one multiply-add per MAC).  The split-precision mode issues three 16-bit MFMAs
             # per product (the exact-f32 mode: the 8x slower fp32 MFMA), so the matrix pipes are busier than `frac` says by this factor:
-            "mfma_instructions_per_product": {"bf16x3": 3, "bf16": 1, "f32": 1}[args.dtype],
-            "mfma_work_frac_of_peak": round({"bf16x3": 3.0, "bf16": 1.0, "f32": 1.0}[args.dtype] * tflops / BF16_MFMA_PEAK_TFLOPS, 4) if args.dtype != "f32" else None, "traffic": traffic, "traffic_source": traffic_source, "pmc_in_network": pmc_extra,
+            "mfma_instructions_per_product": {"bf16x3": 3, "f16x3": 3, "bf16": 1, "f32": 1}[args.dtype],
+            "mfma_work_frac_of_peak": round({"bf16x3": 3.0, "f16x3": 3.0, "bf16": 1.0, "f32": 1.0}[args.dtype] * tflops / BF16_MFMA_PEAK_TFLOPS, 4) if args.dtype != "f32" else None, "traffic": traffic, "traffic_source": traffic_source, "pmc_in_network": pmc_extra,
             "launches": cnt, "avg_launch_us": round(us / cnt, 2), "algorithmic_gflop_per_launch": round(gf / cnt, 3),
             "algorithmic_bytes_per_launch": round(mb / cnt * 1e6),
             "share_of_profiled_conv_time": round(us / max(sum(v[1] for v in grp.values()), 1e-9), 3),
@@ -624,9 +627,9 @@ def main():
                     "mfma_work_frac_of_peak": round(per_product * rf["achieved"] / BF16_MFMA_PEAK_TFLOPS, 4) if rf.get("achieved") else None,
                     "all_conv_classes": rf.get("all_conv_classes"),
                     "hbm_bound_classes": {k: v for k, v in (rf.get("hbm_bound_classes") or {}).items() if k.startswith("gn")}}
-        others = [d for d in ("bf16x3", "bf16", "f32") if d != args.dtype]
+        others = [d for d in ("f16x3", "bf16x3", "bf16", "f32") if d != args.dtype]
         for d in others:
-            name = {"bf16x3": "bf16x3_parity_mode", "bf16": "bf16_throughput_mode", "f32": "f32_parity_mode"}[d]
+            name = {"f16x3": "f16x3_parity_mode", "bf16x3": "bf16x3_parity_mode", "bf16": "bf16_throughput_mode", "f32": "f32_parity_mode"}[d]
             try:
                 if d == "f32":
                     leg = sub_leg("f32", 4, ["--no-roofline", "--no-graph-leg"])
@@ -635,11 +638,15 @@ def main():
                 o = {"value": leg["value"], "unit": "images/s", "dtype": d, "ms_per_step": leg["ms_per_step"], "steps": leg["steps"],
                      "over_headline": round(leg["value"] / images_per_s, 3), "achieved_tflops_whole_step": leg["achieved_tflops_whole_step"]}
                 if d != "f32":
-                    o["roofline"] = leg_roofline(leg.get("roofline"), 3.0 if d == "bf16x3" else 1.0)
+                    o["roofline"] = leg_roofline(leg.get("roofline"), 3.0 if d in ("bf16x3", "f16x3") else 1.0)
                 if d == "bf16":
                     o["hipgraph_replay"] = leg.get("hipgraph_replay")
                     o["note"] = ("same workload, protocol and code path (python bench.py --dtype bf16): bf16 activations and MFMA inputs -- NOT tolerance-compliant (|dPSNR| ~1e-2 dB "
                                  "against the f32 arithmetic end to end, per-call PSNR floors in tests/test_fullsize_gpu.py::test_e2e_teacher_forced); a throughput figure, not the headline")
+                elif d == "f16x3":
+                    o["x3_fallbacks"] = leg.get("x3_fallbacks")
+                    o["note"] = ("same workload, protocol and code path (python bench.py --dtype f16x3): fp32 activations, every conv as 3 fp16 MFMAs per product (fp16 head + fp16 tails, 11 + 11-bit "
+                                 "operands), fp32 accumulation; every guided call polls the fp16-window flag and is redone in the bf16x3 arithmetic when an operand left the window (x3_fallbacks)")
                 elif d == "f32":
                     o["note"] = "same workload, protocol and code path (python bench.py --dtype f32 --steps 4): fp32 activations + v_mfma_f32_32x32x2_f32, the reference's own arithmetic"
                 else:

@@ -28,6 +28,13 @@ extern "C" {
 enum { KDIP_OK = 0, KDIP_ERR_ARG = -1, KDIP_ERR_HIP = -2, KDIP_ERR_STATE = -3, KDIP_ERR_NOMEM = -4,
        KDIP_ERR_UNSUPPORTED = -5 };
 enum { KDIP_F32 = 0, KDIP_BF16 = 1,                   /* storage / MFMA input type of the UNet */
+       KDIP_F16X3 = 3,      /* as KDIP_BF16X3 with an fp16 HEAD as well: a*b = f16(a)*f16(b) + f16(a)*f16(b - f16(b)) + f16(a - f16(a))*f16(b), three fp16
+                             * MFMAs, 11 + 11-bit operands (operand error ~2^-22; two staged operand planes instead of three, no weight re-encode:
+                             * 3.6 % faster end to end).  The head has fp16's exponent range only: an activation / gradient operand beyond +-65504
+                             * after its power-of-two scaling SATURATES its products instead of degrading them.  Every such launch raises bit 0 of
+                             * kdip_unet_x3_saturated, the handle carries the KDIP_BF16X3 weights as well, and kdip_unet_x3_head(u, 1) makes the
+                             * next calls run on them: callers poll the flag per call and redo a flagged call bf16-headed (kdip_amd/unet.py does),
+                             * so the fast arithmetic never decides a result outside its window.  Deterministic like KDIP_BF16X3. */
        KDIP_BF16X3 = 2 };   /* fp32 storage, split-precision convs: every product a*b as three 16-bit MFMAs into one fp32 accumulator --
                              * bf16(a)*bf16(b) + f16(a)*f16(b - bf16(b)) + f16(a - bf16(a))*f16(bf16(b)) (bf16 head, fp16 tails with
                              * power-of-two range scaling; csrc/conv.hip Mma<f32x3_t>): operand error ~2^-21 of the tensor's scale instead
@@ -86,6 +93,10 @@ int kdip_unet_x3_window(kdip_unet* u, int per_launch);
  * bit 1: a weight of this handle was outside the window when it was packed (|w| > 255.9).  0 = every product of every conv carried its
  * full split precision.  Synchronises `stream`. */
 int kdip_unet_x3_saturated(kdip_unet* u, void* stream, int reset, int* flags_host);
+/* (no reference counterpart) KDIP_F16X3 handles: bf16_head = 1 -> the following kdip_unet_forward / kdip_unet_vjp / kdip_guided_call_v1 run in the
+ * KDIP_BF16X3 arithmetic on the bf16-headed weights the handle carries (same workspace plan, same activation stash: a VJP may be redone
+ * after a forward made in the other arithmetic); 0 -> back to the fp16-headed arithmetic (default).  Returns the previous setting or < 0. */
+int kdip_unet_x3_head(kdip_unet* u, int bf16_head);
 /* (no reference counterpart) A/B switch of the fixed-order reductions of a KDIP_F32 / KDIP_BF16X3 handle (default on; off = the
  * floating-point atomics of the KDIP_BF16 mode: measures what reproducibility costs).  Returns the previous setting (0 | 1) or < 0. */
 int kdip_unet_deterministic(kdip_unet* u, int on);

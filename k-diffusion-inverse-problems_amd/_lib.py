@@ -27,6 +27,7 @@ SIGNATURES = {
     "kdip_unet_x3_window": (C.c_int, [VP, C.c_int]),
     "kdip_unet_deterministic": (C.c_int, [VP, C.c_int]),
     "kdip_unet_x3_saturated": (C.c_int, [VP, VP, C.c_int, C.POINTER(C.c_int)]),
+    "kdip_unet_x3_head": (C.c_int, [VP, C.c_int]),
     "kdip_op_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(VP)]),
     "kdip_op_destroy": (None, [VP]),
     "kdip_op_set_psf": (C.c_int, [VP, VP, C.c_int, C.c_int]),
@@ -86,8 +87,8 @@ SIGNATURES = {
     "kdip_test_groupnorm": (C.c_int, [VP, C.c_int, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, VP, C.c_int, VP, VP, VP]),
 }
 
-F32, BF16, BF16X3 = 0, 1, 2
-DTYPES = {"f32": F32, "bf16": BF16, "bf16x3": BF16X3}      # include/kdip.h: KDIP_F32 / KDIP_BF16 / KDIP_BF16X3
+F32, BF16, BF16X3, F16X3 = 0, 1, 2, 3
+DTYPES = {"f32": F32, "bf16": BF16, "bf16x3": BF16X3, "f16x3": F16X3}      # include/kdip.h: KDIP_F32 / KDIP_BF16 / KDIP_BF16X3 / KDIP_F16X3
 OP_INPAINT, OP_BLUR, OP_SR = 0, 1, 2
 GWS_OUT6, GWS_X0_MEAN, GWS_X0_RAW, GWS_VAR, GWS_MAT, GWS_COT, GWS_G_RAW, GWS_UG, GWS_SCORE, GWS_COUNT = range(10)      # include/kdip.h KDIP_GWS_*
 OT_NONE, OT_DWT, OT_DCT = 0, 1, 2

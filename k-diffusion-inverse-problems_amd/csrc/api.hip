@@ -38,7 +38,7 @@ int kdip_unet_create(int device, int dtype, int image_size, int in_channels, int
                      int num_res_blocks, const int* attention_ds, int n_attention_ds, const int* channel_mult,
                      int n_channel_mult, int num_head_channels, kdip_unet** out) {
   KDIP_REQUIRE(out, "null output handle");
-  KDIP_REQUIRE(dtype == KDIP_F32 || dtype == KDIP_BF16 || dtype == KDIP_BF16X3, "dtype %d", dtype);
+  KDIP_REQUIRE(dtype == KDIP_F32 || dtype == KDIP_BF16 || dtype == KDIP_BF16X3 || dtype == KDIP_F16X3, "dtype %d", dtype);
   KDIP_REQUIRE(in_channels == 3 && out_channels <= 32, "in_channels must be 3, out_channels <= 32");
   KDIP_REQUIRE(model_channels % 32 == 0, "model_channels must be a multiple of 32");
   int ndev = 0;
@@ -47,7 +47,8 @@ int kdip_unet_create(int device, int dtype, int image_size, int in_channels, int
   kdip_unet* h = new kdip_unet();
   h->u.device = device;
   h->u.dt = dtype == KDIP_BF16 ? DT_BF16 : DT_F32;
-  h->u.cdt = dtype == KDIP_BF16X3 ? DT_F32X3 : h->u.dt;
+  h->u.cdt = dtype == KDIP_BF16X3 ? DT_F32X3 : (dtype == KDIP_F16X3 ? DT_F32H3 : h->u.dt);
+  h->u.has_alt = dtype == KDIP_F16X3;      // ... carries the bf16-headed weights too (kdip_unet_x3_head)
   h->u.det = dtype != KDIP_BF16;        // fp32-storage modes: fixed-order reductions (det.h)
   if (const char* e = getenv("KDIP_DET")) { if (atoi(e) == 0) h->u.det = false; }      // A/B timing aid (same as kdip_unet_deterministic(u, 0))
   h->u.cfg.image_size = image_size; h->u.cfg.in_channels = in_channels; h->u.cfg.model_channels = model_channels;
@@ -108,7 +109,7 @@ int kdip_unet_debug_stash_checksum(kdip_unet* u, void* stream, unsigned long lon
 long kdip_unet_workspace_generation(kdip_unet* u) { return u ? u->u.ws_generation : -1; }
 int kdip_unet_x3_window(kdip_unet* u, int per_launch) {
   KDIP_REQUIRE(u, "null handle");
-  KDIP_REQUIRE(u->u.cdt == DT_F32X3, "x3_window: the handle was not created with KDIP_BF16X3");
+  KDIP_REQUIRE(is_x3(u->u.cdt), "x3_window: the handle was not created with KDIP_BF16X3 / KDIP_F16X3");
   if (u->u.x3_window_per_launch != (per_launch ? 1 : 0)) {
     u->u.x3_window_per_launch = per_launch ? 1 : 0;
     u->u.planned.clear();              // the per-launch words live in the zeros arena: re-plan every batch
@@ -119,7 +120,7 @@ int kdip_unet_x3_window(kdip_unet* u, int per_launch) {
 }
 int kdip_unet_x3_saturated(kdip_unet* u, void* stream, int reset, int* flags_host) {
   KDIP_REQUIRE(u && flags_host, "null argument");
-  KDIP_REQUIRE(u->u.cdt == DT_F32X3 && u->u.x3_sat, "x3_saturated: the handle was not created with KDIP_BF16X3 (or is not finalized)");
+  KDIP_REQUIRE(is_x3(u->u.cdt) && u->u.x3_sat, "x3_saturated: the handle was not created with KDIP_BF16X3 / KDIP_F16X3 (or is not finalized)");
   KDIP_HIP_CHECK(hipSetDevice(u->u.device));
   unsigned w = 0;
   KDIP_HIP_CHECK(hipMemcpyAsync(&w, u->u.x3_sat, sizeof(w), hipMemcpyDeviceToHost, ST(stream)));
@@ -127,6 +128,13 @@ int kdip_unet_x3_saturated(kdip_unet* u, void* stream, int reset, int* flags_hos
   KDIP_HIP_CHECK(hipStreamSynchronize(ST(stream)));
   *flags_host = (int)(w & 1u) | (u->u.x3_weight_sat > 0 ? 2 : 0);
   return KDIP_OK;
+}
+int kdip_unet_x3_head(kdip_unet* u, int bf16_head) {
+  if (!u) return set_error(KDIP_ERR_ARG, "null handle");
+  if (!u->u.has_alt) return set_error(KDIP_ERR_STATE, "x3_head: the handle was not created with KDIP_F16X3");
+  const int prev = u->u.x3_alt ? 1 : 0;
+  u->u.x3_alt = bf16_head != 0;
+  return prev;
 }
 int kdip_unet_deterministic(kdip_unet* u, int on) {
   KDIP_REQUIRE(u, "null handle");
@@ -377,7 +385,7 @@ int kdip_debug_conv_timing(void* dev_buf, int H, int cin, int cout, int st_mode)
 int kdip_test_conv(void* stream, int dtype, int ntaps, const float* x_nchw, int B, int Cin, int H, int W, const float* w_host,
                    const float* bias_host, int Cout, int transpose_flip, float* y_nchw, int storage_out) {
   hipStream_t st = ST(stream);
-  const DType cdt = dtype == KDIP_BF16 ? DT_BF16 : (dtype == KDIP_BF16X3 ? DT_F32X3 : DT_F32);      // conv arithmetic
+  const DType cdt = dtype == KDIP_BF16 ? DT_BF16 : (dtype == KDIP_BF16X3 ? DT_F32X3 : (dtype == KDIP_F16X3 ? DT_F32H3 : DT_F32));      // conv arithmetic
   const DType dt = storage_dtype(cdt);
   size_t es = dt == DT_BF16 ? 2 : 4;
   // logical conv after optional transpose: Ci -> Co
@@ -396,7 +404,7 @@ int kdip_test_conv(void* stream, int dtype, int ntaps, const float* x_nchw, int 
   // operand follows max |x|; forward inputs are taken at O(1) scale
   ConvStats stt;
   unsigned* amax = nullptr;
-  if (cdt == DT_F32X3 && transpose_flip) {
+  if (is_x3(cdt) && transpose_flip) {
     KDIP_HIP_CHECK(hipMalloc((void**)&amax, sizeof(unsigned)));
     if (!rc) rc = amax_bits(st, x_nchw, (long)B * Ci * H * W, amax);
     stt.x3_amax = amax;
@@ -427,7 +435,7 @@ int kdip_conv_create(int device, int dtype, const float* w_host, const float* bi
   KDIP_REQUIRE(out && w_host && (ntaps == 9 || ntaps == 1) && Cout > 0 && Cin > 0, "conv_create: bad arguments");
   KDIP_HIP_CHECK(hipSetDevice(device));
   kdip_conv* c = new kdip_conv;
-  c->cdt = dtype == KDIP_BF16 ? DT_BF16 : (dtype == KDIP_BF16X3 ? DT_F32X3 : DT_F32); c->dt = storage_dtype(c->cdt); c->cin = Cin; c->cout = Cout; c->cin_pad = pad32i(Cin); c->ntaps = ntaps; c->device = device;
+  c->cdt = dtype == KDIP_BF16 ? DT_BF16 : (dtype == KDIP_BF16X3 ? DT_F32X3 : (dtype == KDIP_F16X3 ? DT_F32H3 : DT_F32)); c->dt = storage_dtype(c->cdt); c->cin = Cin; c->cout = Cout; c->cin_pad = pad32i(Cin); c->ntaps = ntaps; c->device = device;
   std::vector<char> buf(packed_weight_bytes(c->cdt, ntaps, c->cin_pad, Cout));
   pack_conv_weight(c->cdt, w_host, Cout, Cin, ntaps, 0, c->cin_pad, buf.data());
   bool ok = hipMalloc(&c->w, buf.size()) == hipSuccess && hipMemcpy(c->w, buf.data(), buf.size(), hipMemcpyHostToDevice) == hipSuccess;

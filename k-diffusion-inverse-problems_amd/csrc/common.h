@@ -16,9 +16,14 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 // DT_F32X3: fp32 STORAGE with split-bf16 conv arithmetic (operands split into bf16 hi + lo, hi*hi + hi*lo + lo*hi on the bf16 MFMA,
 // fp32 accumulate: ~2^-17 relative operand error instead of bf16's 2^-9).  Only conv_forward / pack_conv_weight /
 // packed_weight_bytes take it; every other kernel of that mode runs its DT_F32 instantiation.
-enum DType { DT_F32 = 0, DT_BF16 = 1, DT_F32X3 = 2 };
+// DT_F32H3: the same with an fp16 HEAD as well (three fp16 MFMAs per product, 11 + 11-bit operands: two A planes instead of three, no weight-head
+// re-encode) -- faster and more accurate inside the fp16 window, but an operand beyond +-65504 after scaling saturates the product instead of
+// degrading it; handles of this mode carry the DT_F32X3 weights as well and callers redo a flagged call with them (unet.h: x3_alt).
+enum DType { DT_F32 = 0, DT_BF16 = 1, DT_F32X3 = 2, DT_F32H3 = 3 };
+inline bool is_x3(DType dt) { return dt == DT_F32X3 || dt == DT_F32H3; }
 inline DType storage_dtype(DType dt) { return dt == DT_BF16 ? DT_BF16 : DT_F32; }
 struct f32x3_t { float v; };       // kernel tag type of DT_F32X3: an fp32 element
+struct f32h3_t { float v; };       // kernel tag type of DT_F32H3
 
 // status codes: the global KDIP_* enum of include/kdip.h (included above)
 
@@ -68,10 +73,12 @@ template <> struct TypeInfo<bf16_t> {
 __device__ inline float to_f32(float v) { return v; }
 __device__ inline float to_f32(bf16_t v) { return bf16_to_f32(v); }
 __device__ inline float to_f32(f32x3_t v) { return v.v; }
+__device__ inline float to_f32(f32h3_t v) { return v.v; }
 template <typename T> __device__ inline T from_f32(float v);
 template <> __device__ inline float from_f32<float>(float v) { return v; }
 template <> __device__ inline bf16_t from_f32<bf16_t>(float v) { return f32_to_bf16(v); }
 template <> __device__ inline f32x3_t from_f32<f32x3_t>(float v) { return f32x3_t{v}; }
+template <> __device__ inline f32h3_t from_f32<f32h3_t>(float v) { return f32h3_t{v}; }
 
 // 16-byte vector <-> float[EPV]
 template <typename T> __device__ inline void unpack16(const uint4& v, float* out);

@@ -66,6 +66,13 @@ template <> struct Mma<float> {
 //   element outside the fp16 window loses (part of) its cross terms, i.e. degrades towards the bf16 head's 2^-9, never to inf.
 //   A planes in LDS: bf16 a_hi*SA | f16 a*SA | f16 a_lo*SA; B planes (packed weights): bf16 b_hi*S | f16 b_lo*S, and the
 //   scaled head is re-encoded bf16 -> f16 in registers (exact: 8 significant bits, |w * 2^8| < 65504).
+// DT_F32H3 (tag f32h3_t; round 6): fp16 HEAD as well -- a16 = f16(a*SA), a_lo = f16(a*SA - a16), likewise b (11 + 11 bits each):
+//   acc += a16*b16 + a16*b_lo + a_lo*b16, three v_mfma_f32_32x32x16_f16.  Two A planes instead of three (a third less LDS traffic and staging
+//   work) and no weight-head re-encode (40 % of the K loop's VALU instructions), operand error ~2^-22 (conv error vs fp64 4.7e-7 against 7e-7)
+//   -- but the head no longer carries the fp32 exponent range: an operand beyond +-65504 after scaling SATURATES the product instead of
+//   degrading it to the bf16 head's 2^-9 (operands below 2^-14 only lose relative precision: absolute error <= 2^-25 of the tensor scale).  Every
+//   launch reports such an operand through ConvParams::x3_sat, and the owners of DT_F32H3 handles redo a flagged call with the bf16-headed
+//   weights they carry as well (UNet::x3_alt, kdip_amd/unet.py): the fast arithmetic never decides a result outside its window.
 // KDIP_X3_MIXED 0: plain bf16 split, a_hi*b_hi + a_hi*bf16(b_lo) + bf16(a_lo)*b_hi: operand error ~2^-18 (8 x the mixed
 //   form's), no range window at all.
 #ifndef KDIP_X3_MIXED
@@ -109,6 +116,19 @@ template <> struct Mma<f32x3_t> {
 #endif
   }
 };
+template <> struct Mma<f32h3_t> {
+  static constexpr int KSTEP = 16;
+  static constexpr int NPA = 2, NPB = 2, NTERM = 3, LDS_BPC = 2 * NPA;
+  template <int TERM> __device__ static inline void run(const uint4 (&a)[2], const uint4 (&b)[2], const uint4&, f32x16& c) {
+    constexpr int pa = TERM == 2 ? 1 : 0, pb = TERM == 1 ? 1 : 0;      // a16*b16, a16*b_lo, a_lo*b16
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[pa]), __builtin_bit_cast(f16x8, b[pb]), c, 0, 0, 0);
+  }
+};
+// split-precision kernel tags: fp32 storage; XMODE 1 = bf16 head + fp16 tails (0: the plain bf16 split of -DKDIP_X3_MIXED=0 builds), 2 = fp16 head + fp16 tail
+template <typename T> struct X3Tag { static constexpr bool is = false; static constexpr int mode = 0; };
+template <> struct X3Tag<f32x3_t> { static constexpr bool is = true; static constexpr int mode = KDIP_X3_MIXED ? 1 : 0; };
+template <> struct X3Tag<f32h3_t> { static constexpr bool is = true; static constexpr int mode = 2; };
+
 
 #ifndef KDIP_TIMING
 #define KDIP_TIMING 0      // diagnostic build: per-block phase timestamps (kdip_debug_conv_timing)
@@ -183,7 +203,7 @@ constexpr int KC = 32;            // input channels per B-pipeline stage (one ta
                                   // steps, interleaved): KC 16 alone +-0; KC 16 + 3 blocks per CU 101.6 -> 97.8 ms per step, 128 -> 128 @ 256^2 509 -> 488 us.  The narrower
                                   // tiles (128x64 / 128x32: small maps) keep 32-channel stages (16: 6.7 -> 7.0 ms per step for the 128x64 class).
 // channels per sub-chunk of an instantiation (TILE = MT * NT accumulator tiles per wave)
-template <typename T, int NTAPS, int TILE> constexpr int kc_of() { return (std::is_same<T, f32x3_t>::value && NTAPS == 9 && TILE == 4) ? KDIP_X3_KC : KC; }
+template <typename T, int NTAPS, int TILE> constexpr int kc_of() { return (X3Tag<T>::is && NTAPS == 9 && TILE == 4) ? KDIP_X3_KC : KC; }
 #ifndef KDIP_CONV1_NT_LOAD
 #define KDIP_CONV1_NT_LOAD 0     // non-temporal input staging loads of the 1x1 convs: big-map class -3 %, small-map classes +2-4 %, step unchanged
 #endif
@@ -727,10 +747,11 @@ __device__ __forceinline__ void epilogue_f32_fast(const ConvParams& p, f32x16 (&
 // transform's registers do not fit next to the two-deep weight pipeline of the plain one)
 // TFM 2: GroupNorm-backward staging of a dgrad conv (two tensors staged: dz and the GroupNorm input; ConvParams::tf_mode 2)
 template <typename T, int NTAPS, int WAVES_M, int WAVES_N, int MT, int NT, int SUBS, int TFM = 0>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::value) ? (MT * NT == 4 ? KDIP_X3_OCC : 2) : (sizeof(T) == 2 && NTAPS == 9) ? (MT * NT == 4 ? KDIP_OCC : (MT * NT == 8 ? 2 : 1)) : ((sizeof(T) == 2 && NTAPS == 1 && MT * NT == 4 && SUBS == 2) ? 3 : 1)) void conv_igemm_kernel(ConvParams p) {
-  constexpr bool X3 = std::is_same<T, f32x3_t>::value;     // fp32 storage, operands split into bf16 hi / lo planes on the way into LDS
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (X3Tag<T>::is) ? (MT * NT == 4 ? KDIP_X3_OCC : 2) : (sizeof(T) == 2 && NTAPS == 9) ? (MT * NT == 4 ? KDIP_OCC : (MT * NT == 8 ? 2 : 1)) : ((sizeof(T) == 2 && NTAPS == 1 && MT * NT == 4 && SUBS == 2) ? 3 : 1)) void conv_igemm_kernel(ConvParams p) {
+  constexpr bool X3 = X3Tag<T>::is;                        // fp32 storage, operands split into 16-bit hi / lo planes on the way into LDS
+  constexpr int XMODE = X3Tag<T>::mode;                    // 1: bf16 head + fp16 tails, 2: fp16 head + fp16 tail
   constexpr int NPA = Mma<T>::NPA, NPB = Mma<T>::NPB, NTERM = Mma<T>::NTERM;
-  constexpr bool X3M = X3 && KDIP_X3_MIXED;                // bf16 head + fp16 tails
+  constexpr bool X3M = X3 && XMODE != 0;                   // fp16 planes: power-of-two operand scaling + window watch
   constexpr int NTHREADS = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * MT * 32;
   constexpr int BN = WAVES_N * NT * 32;
@@ -961,10 +982,18 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
             for (int e = 0; e < 4; ++e) f[e] *= x3_sa;
           }
           if constexpr (X3M) x3_peak = fmaxf(x3_peak, fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3]))));
+          unsigned char* d = smem + buf * abuf_bytes + pix * PIXB + ((pix * p.magicRow) >> 20) * p.rowpad + (v % VPP) * 8;
+          if constexpr (XMODE == 2) {                    // fp16 head + fp16 tail (two planes)
+            typedef _Float16 h2t __attribute__((ext_vector_type(2)));
+            const uint32_t g0 = pack_f16x2_sat(f[0], f[1]), g1 = pack_f16x2_sat(f[2], f[3]);
+            const h2t q0 = __builtin_bit_cast(h2t, g0), q1 = __builtin_bit_cast(h2t, g1);
+            *(uint2*)d = make_uint2(g0, g1);
+            *(uint2*)(d + KCH * 2) = make_uint2(pack_f16x2_sat(f[0] - (float)q0[0], f[1] - (float)q0[1]), pack_f16x2_sat(f[2] - (float)q1[0], f[3] - (float)q1[1]));
+            continue;
+          }
           const uint32_t h0 = pack_bf16x2(f[0], f[1]), h1 = pack_bf16x2(f[2], f[3]);
           const float r0 = f[0] - __uint_as_float(h0 << 16), r1 = f[1] - __uint_as_float(h0 & 0xffff0000u);
           const float r2 = f[2] - __uint_as_float(h1 << 16), r3 = f[3] - __uint_as_float(h1 & 0xffff0000u);
-          unsigned char* d = smem + buf * abuf_bytes + pix * PIXB + ((pix * p.magicRow) >> 20) * p.rowpad + (v % VPP) * 8;
           *(uint2*)d = make_uint2(h0, h1);
           if constexpr (X3M) {
             *(uint2*)(d + KCH * 2) = make_uint2(pack_f16x2_sat(f[0], f[1]), pack_f16x2_sat(f[2], f[3]));
@@ -1060,7 +1089,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (std::is_same<T, f32x3_t>::v
         for (int ks = 0; ks < KS; ++ks) {
           uint4 bh[NT];                                  // mixed split precision: the weight head re-encoded as f16 (once per fragment)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) bh[nt] = X3M ? bf16x8_to_f16x8(bq[0][ks][nt][0]) : make_uint4(0, 0, 0, 0);
+          for (int nt = 0; nt < NT; ++nt) bh[nt] = XMODE == 1 ? bf16x8_to_f16x8(bq[0][ks][nt][0]) : make_uint4(0, 0, 0, 0);
 #define KDIP_MMA_PASS(TERM)                                                                                      \
           _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                      \
           _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                      \
@@ -1350,7 +1379,7 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
   // 32-pixel-wide patches: an MFMA m-tile (32 rows) is one patch row, so the 16-lane groups of
   // ds_read_b128 see 16 consecutive pixels (5-slot stride -> conflict free); 16-wide patches put two
   // patch rows in one m-tile and collide on 2 of 16 slots.
-  const int tw_pref = std::is_same<T, f32x3_t>::value ? KDIP_X3_TW : KDIP_TW;
+  const int tw_pref = X3Tag<T>::is ? KDIP_X3_TW : KDIP_TW;
   int TW = p.W < tw_pref ? p.W : tw_pref;
   int TH = p.H < BM / TW ? p.H : BM / TW;
   int TB = BM / (TH * TW);
@@ -1405,7 +1434,7 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
     return set_error(KDIP_ERR_UNSUPPORTED, "conv: fused GroupNorm statistics not available for this shape");
   int nblkN = cdiv(p.ntilesN * 32, BN);
   long grid = (long)p.mtiles * nblkN;
-  constexpr bool TF_OK = std::is_same<T, f32x3_t>::value && NTAPS == 9 && SUBS == 1;
+  constexpr bool TF_OK = X3Tag<T>::is && NTAPS == 9 && SUBS == 1;
   if (p.tf_coef && !(TF_OK && TB == 1)) return set_error(KDIP_ERR_UNSUPPORTED, "conv: fused GroupNorm staging is not available for this shape");
   auto kern = (TF_OK && p.tf_coef) ? (p.tf_mode == 2 ? conv_igemm_kernel<T, NTAPS, WAVES_M, WAVES_N, MT, NT, SUBS, (TF_OK ? 2 : 0)> : conv_igemm_kernel<T, NTAPS, WAVES_M, WAVES_N, MT, NT, SUBS, (TF_OK ? 1 : 0)>)
                                    : conv_igemm_kernel<T, NTAPS, WAVES_M, WAVES_N, MT, NT, SUBS, 0>;
@@ -1430,7 +1459,7 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
     KDIP_HIP_CHECK(hipGetDevice(&dev));
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(granted.load(std::memory_order_acquire) & bit)) {
-      KDIP_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((std::is_same<T, f32x3_t>::value ? 128 : 96) * 1024)));
+      KDIP_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((X3Tag<T>::is ? 128 : 96) * 1024)));
       granted.fetch_or(bit, std::memory_order_release);
     }
   }
@@ -1481,7 +1510,7 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
   if (splits > 1) {
     const long npix = (long)p.B * p.H * p.W;
     long g = (npix * (p.Cout / 4) + 255) / 256; if (g > 4096) g = 4096;
-    using ST = std::conditional_t<std::is_same<T, f32x3_t>::value, float, T>;      // storage type
+    using ST = std::conditional_t<X3Tag<T>::is, float, T>;      // storage type
     hipLaunchKernelGGL(conv_splitk_finalize_kernel<ST>, dim3((unsigned)g), dim3(256), 0, st, p.sk_ws, p.bias, (const ST*)p.res, p.ldr, npix, p.Cout,
                        (ST*)p.y, p.ldy, p.sk_det ? splits : 0);
   }
@@ -1507,9 +1536,9 @@ static int launch_cfg(ConvParams& p, hipStream_t st) {
     // split precision, 128 x 32 tile (small maps): the staging runs ONE chunk ahead, so a K loop of Cin / 32 chunks is a chain of Cin / 32 memory
     // round trips (16^2 1024 -> 512: 32 us for 2 GFLOP); 64-channel chunks halve the chain (102 KB of LDS: one block per CU, which is all
     // these launches have anyway)
-    if (KDIP_X3_SUBS1_SMALL >= 2 && std::is_same<T, f32x3_t>::value && MT * NT == 1 && p.Cin % 64 == 0) return launch_cfg2<T, NTAPS, WAVES_M, WAVES_N, MT, NT, (NTAPS == 1 ? 2 : 1)>(p, st);
+    if (KDIP_X3_SUBS1_SMALL >= 2 && X3Tag<T>::is && MT * NT == 1 && p.Cin % 64 == 0) return launch_cfg2<T, NTAPS, WAVES_M, WAVES_N, MT, NT, (NTAPS == 1 ? 2 : 1)>(p, st);
     // split precision: 64 channels (12 MFMAs per accumulator) per barrier
-    if (KDIP_X3_SUBS1 >= 2 && std::is_same<T, f32x3_t>::value && p.Cin % 64 == 0) return launch_cfg2<T, NTAPS, WAVES_M, WAVES_N, MT, NT, (NTAPS == 1 ? 2 : 1)>(p, st);
+    if (KDIP_X3_SUBS1 >= 2 && X3Tag<T>::is && p.Cin % 64 == 0) return launch_cfg2<T, NTAPS, WAVES_M, WAVES_N, MT, NT, (NTAPS == 1 ? 2 : 1)>(p, st);
   }
 #if KDIP_SUBS3 > 1
   if (NTAPS == 9 && sizeof(T) == 2 && MT * NT == 4 && p.Cin % (32 * KDIP_SUBS3) == 0)
@@ -1536,13 +1565,13 @@ static int launch_T(ConvParams& p, hipStream_t st) {
   const long mt = cdiv((long)p.B * p.H * p.W, 128);
   // (a 256x128 block with 128x64 wave tiles and a 1x4 wave layout were measured and rejected: DESIGN.md section 5,
   // tools/experiments/)
-  if constexpr (KDIP_X3_LAYOUT14 && std::is_same<T, f32x3_t>::value && NTAPS == 9) {
+  if constexpr (KDIP_X3_LAYOUT14 && X3Tag<T>::is && NTAPS == 9) {
     if (npad >= 128 && mt * cdiv(npad, 128) >= 512) return launch_cfg<T, NTAPS, 1, 4, 4, 1>(p, st);
   }
   if (npad >= 128 && mt * cdiv(npad, 128) >= 512) return launch_cfg<T, NTAPS, 2, 2, 2, 2>(p, st);
   if (npad >= 64 && mt * cdiv(npad, 64) >= 512) return launch_cfg<T, NTAPS, 2, 2, 2, 1>(p, st);
   // (split precision, 8 x 8 maps at 8 images -- 4 m-tiles: the 128 x 64 tile + 16 K splits measures 27.1 vs 32.9 us on 512 -> 512, tools/r06_smallmap_scan.sh)
-  if (std::is_same<T, f32x3_t>::value && NTAPS == 9 && npad >= 128 && mt <= 4 && p.sk_ws) return launch_cfg<T, NTAPS, 2, 2, 2, 1>(p, st);
+  if (X3Tag<T>::is && NTAPS == 9 && npad >= 128 && mt <= 4 && p.sk_ws) return launch_cfg<T, NTAPS, 2, 2, 2, 1>(p, st);
   if (npad >= 128 && mt * cdiv(npad, 32) < 256) return launch_cfg<T, NTAPS, 4, 1, 1, 1>(p, st);
   if (npad >= 64 && mt * cdiv(npad, 32) >= 512) return launch_cfg<T, NTAPS, 4, 1, 1, 1>(p, st);
   if (npad >= 128) return launch_cfg<T, NTAPS, 2, 2, 2, 1>(p, st);
@@ -1574,7 +1603,7 @@ int conv_forward(hipStream_t st, DType dt, int ntaps, const void* x, long ldx, i
   p.tf_mode = (stt && stt->tf_coef) ? stt->tf_mode : 0; p.tf_x2 = stt ? stt->tf_x2 : nullptr;
   KDIP_REQUIRE(!p.tf_coef || p.tf_mode == 1 || (p.tf_mode == 2 && p.tf_x2 && ((uintptr_t)p.tf_x2 % 16) == 0 && !p.in_ups),
                "conv: GroupNorm-backward staging needs the GroupNorm input tensor (same layout as the conv input)");
-  KDIP_REQUIRE(!p.tf_coef || (dt == DT_F32X3 && ntaps == 9 && (long)H * W >= 128 && ((uintptr_t)p.tf_coef % 16) == 0),
+  KDIP_REQUIRE(!p.tf_coef || (is_x3(dt) && ntaps == 9 && (long)H * W >= 128 && ((uintptr_t)p.tf_coef % 16) == 0),
                "conv: fused GroupNorm staging needs the split-precision 3x3 kernel and one image per tile");
   p.sk_ws = sk_ws; p.sk_ws_floats = sk_ws_floats; p.sk_splits = 1;
   KDIP_REQUIRE(!(p.in_ups || p.res_ups) || (H % 2 == 0 && W % 2 == 0), "conv: fused x2 upsample needs even H, W");
@@ -1592,6 +1621,7 @@ int conv_forward(hipStream_t st, DType dt, int ntaps, const void* x, long ldx, i
   }
   if (dt == DT_BF16) return ntaps == 9 ? launch_T<bf16_t, 9>(p, st) : launch_T<bf16_t, 1>(p, st);
   if (dt == DT_F32X3) return ntaps == 9 ? launch_T<f32x3_t, 9>(p, st) : launch_T<f32x3_t, 1>(p, st);
+  if (dt == DT_F32H3) return ntaps == 9 ? launch_T<f32h3_t, 9>(p, st) : launch_T<f32h3_t, 1>(p, st);
   return ntaps == 9 ? launch_T<float, 9>(p, st) : launch_T<float, 1>(p, st);
 }
 
@@ -1627,6 +1657,14 @@ static uint16_t f32_to_f16_bits(float f) {
   return (uint16_t)(sign | (e << 10) | m);
 }
 
+static float f16_bits_to_f32(uint16_t h) {      // exact
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3ffu;
+  float a;
+  if (e == 0) a = (float)m * 5.9604644775390625e-08f;                      // subnormal: m * 2^-24
+  else if (e == 31) a = m ? NAN : INFINITY;
+  else { union { uint32_t u; float f; } c; c.u = ((e + 112u) << 23) | (m << 13); a = c.f; }
+  return sign ? -a : a;
+}
 // split-precision weights outside the fp16 window, counted by pack_conv_weight.  Per host THREAD: UNet::finalize packs a handle's weights on the
 // calling thread and takes the difference across its own packing, so finalizes running concurrently on other threads (multi-stream bench parts,
 // one handle per rank thread) cannot set bit 1 of kdip_unet_x3_saturated on a handle whose own weights were in range.
@@ -1644,7 +1682,7 @@ void pack_conv_weight(DType dt, const float* w, int Cout, int Cin, int ntaps, in
     if (!transpose_flip) return w[((long)n * Cin + k) * ntaps + tap];
     return w[((long)k * Cin + n) * ntaps + (ntaps - 1 - tap)];
   };
-  if (dt == DT_F32X3) {
+  if (is_x3(dt)) {
     bf16_t* o = (bf16_t*)out;
     long idx = 0;
     for (int tap = 0; tap < ntaps; ++tap)
@@ -1653,7 +1691,13 @@ void pack_conv_weight(DType dt, const float* w, int Cout, int Cin, int ntaps, in
           for (int lane = 0; lane < 64; ++lane)
             for (int e = 0; e < 8; ++e) {
               const float v = W(nt * 32 + (lane & 31), ks * 16 + (lane >> 5) * 8 + e, tap) * X3_S;     // exact power-of-two scaling
-              if (KDIP_X3_MIXED && fabsf(v) > 65504.f) ++t_x3_weight_sat;                              // the f16 re-encoded head saturates (|w| > 255.9)
+              if ((KDIP_X3_MIXED || dt == DT_F32H3) && fabsf(v) > 65504.f) ++t_x3_weight_sat;                              // the f16 re-encoded head saturates (|w| > 255.9)
+              if (dt == DT_F32H3) {          // fp16 head + fp16 tail
+                const uint16_t hi16 = f32_to_f16_bits(v);
+                o[idx + lane * 8 + e] = hi16;
+                o[idx + 64 * 8 + lane * 8 + e] = f32_to_f16_bits(v - f16_bits_to_f32(hi16));
+                continue;
+              }
               const bf16_t hi = f32_to_bf16(v);
               o[idx + lane * 8 + e] = hi;
               const float lo = v - bf16_to_f32(hi);

@@ -48,7 +48,7 @@ struct ConvStats {
   const void* gnb_add = nullptr; long gnb_lda = 0;
   int gnb_silu = 0;                // gnb_dz holds dy, not dz: the epilogue applies silu'(a*gx + b) itself (the 1x1 conv is HBM-bound: the arithmetic is free there)
 };
-inline bool conv_tf_eligible(DType cdt, int ntaps, int H, int W, int Cin_pad) { return cdt == DT_F32X3 && ntaps == 9 && (long)H * W >= 128 && Cin_pad % 32 == 0; }
+inline bool conv_tf_eligible(DType cdt, int ntaps, int H, int W, int Cin_pad) { return is_x3(cdt) && ntaps == 9 && (long)H * W >= 128 && Cin_pad % 32 == 0; }
 // true iff conv_forward can fuse statistics for an output of this shape
 inline bool conv_stats_eligible(int H, int W, int Cout) { return (long)H * W >= 128 && Cout % 128 == 0; }
 int conv_forward(hipStream_t st, DType dt, int ntaps, const void* x, long ldx, int B, int H, int W, int Cin,

@@ -19,6 +19,7 @@ struct ConvW {
   int cin = 0, cout = 0, cin_pad = 0, ntaps = 0;
   void* wf = nullptr;      // packed forward weights (device)
   void* wb = nullptr;      // packed dgrad weights (device): cin' = cout (padded to 32), cout' = cin
+  void *wf_alt = nullptr, *wb_alt = nullptr;      // DT_F32H3 handles: the same weights in the bf16-headed encoding (DT_F32X3), for calls redone outside the fp16 window
   int cin_pad_b = 0;       // padded K of the dgrad conv (= pad32(cout))
   float* bias = nullptr;   // device fp32 [cout]
 };
@@ -64,7 +65,12 @@ struct Arena {
 struct UNet {
   UNetConfig cfg;
   DType dt;                         // activation storage type (DT_F32 | DT_BF16)
-  DType cdt;                        // conv arithmetic / packed-weight type: dt, or DT_F32X3 (fp32 storage, split-bf16 MFMA) when dt == DT_F32
+  DType cdt;                        // conv arithmetic / packed-weight type: dt, or DT_F32X3 / DT_F32H3 (fp32 storage, split-precision MFMA) when dt == DT_F32
+  // DT_F32H3 (fp16-headed split: fast, exact only inside the fp16 window) handles carry the bf16-headed weights as well; x3_alt = 1 makes the
+  // next forward / VJP run on them (kdip_unet_x3_head): how a caller redoes a call whose saturation flag came up.  Same tiles, same
+  // workspace plan, same stash: only the conv arithmetic changes.
+  bool has_alt = false, x3_alt = false;
+  DType ccdt() const { return (has_alt && x3_alt) ? DT_F32X3 : cdt; }
   int device = 0;
   std::vector<std::vector<Layer>> inp, out;
   std::vector<Layer> mid;

@@ -202,6 +202,12 @@ int UNet::finalize() {
     std::vector<char> bufb(packed_weight_bytes(cdt, ntaps, c.cin_pad_b, cin));
     pack_conv_weight(cdt, w, cout, cin, ntaps, 1, c.cin_pad_b, bufb.data());
     c.wb = upload(bufb.data(), bufb.size());
+    if (cdt == DT_F32H3) {      // the bf16-headed encoding of the same weights (same size: two 16-bit planes)
+      pack_conv_weight(DT_F32X3, w, cout, cin, ntaps, 0, c.cin_pad, buf.data());
+      c.wf_alt = upload(buf.data(), buf.size());
+      pack_conv_weight(DT_F32X3, w, cout, cin, ntaps, 1, c.cin_pad_b, bufb.data());
+      c.wb_alt = upload(bufb.data(), bufb.size());
+    }
     c.bias = (float*)upload(b, sizeof(float) * cout);
   };
   auto mkgn = [&](GnW& g, const std::string& p, int C) {
@@ -273,20 +279,25 @@ int UNet::finalize() {
         l[((size_t)o * Ci + i) * 9 + t] = dgrad ? w[((size_t)i * cin + o) * 9 + (8 - t)] : w[((size_t)o * cin + i) * 9 + t];
       return l;
     };
-    auto pack1 = [&](const std::vector<float>& w1, int N, int K) -> void* {      // 1x1 conv weights [N][K] -> packed fragments (K padded to 32)
+    // 1x1 conv weights [N][K] -> packed fragments (K padded to 32), in the handle's encoding and (DT_F32H3) in the bf16-headed one
+    auto pack1 = [&](const std::vector<float>& w1, int N, int K, void** main, void** alt) {
       std::vector<char> buf(packed_weight_bytes(cdt, 1, pad32(K), N));
       pack_conv_weight(cdt, w1.data(), N, K, 1, 0, pad32(K), buf.data());
-      return upload(buf.data(), buf.size());
+      *main = upload(buf.data(), buf.size());
+      if (cdt == DT_F32H3) {
+        pack_conv_weight(DT_F32X3, w1.data(), N, K, 1, 0, pad32(K), buf.data());
+        *alt = upload(buf.data(), buf.size());
+      }
     };
-    auto taps_in_k = [&](const std::vector<float>& l, int Co, int Ci) {
+    auto taps_in_k = [&](const std::vector<float>& l, int Co, int Ci, void** main, void** alt) {
       std::vector<float> w1((size_t)Co * 9 * Ci);
       for (int o = 0; o < Co; ++o) for (int i = 0; i < Ci; ++i) for (int t = 0; t < 9; ++t) w1[(size_t)o * 9 * Ci + t * Ci + i] = l[((size_t)o * Ci + i) * 9 + t];
-      return pack1(w1, Co, 9 * Ci);
+      pack1(w1, Co, 9 * Ci, main, alt);
     };
-    auto taps_in_n = [&](const std::vector<float>& l, int Co, int Ci, int Np) {
+    auto taps_in_n = [&](const std::vector<float>& l, int Co, int Ci, int Np, void** main, void** alt) {
       std::vector<float> w1((size_t)Np * Ci, 0.f);
       for (int o = 0; o < Co; ++o) for (int i = 0; i < Ci; ++i) for (int t = 0; t < 9; ++t) w1[((size_t)t * Co + o) * Ci + i] = l[((size_t)o * Ci + i) * 9 + t];
-      return pack1(w1, Np, Ci);
+      pack1(w1, Np, Ci, main, alt);
     };
     const int ic = cfg.in_channels, oc = cfg.out_channels, c0 = inp[0][0].cout, cf = final_ch;
     const float* wi = need("input_blocks.0.0.weight", (long)c0 * ic * 9);
@@ -294,17 +305,17 @@ int UNet::finalize() {
     if (wi && wo) {
       const int nin = pad32(9 * ic), nout = pad32(9 * oc);
       in_k1.ntaps = 1; in_k1.cin = 9 * ic; in_k1.cin_pad = pad32(9 * ic); in_k1.cout = c0; in_k1.bias = inp[0][0].conv.bias;
-      in_k1.wf = taps_in_k(logical(wi, c0, ic, false), c0, ic);
+      taps_in_k(logical(wi, c0, ic, false), c0, ic, &in_k1.wf, &in_k1.wf_alt);
       in_n1.ntaps = 1; in_n1.cin = nin; in_n1.cout = c0; in_n1.cin_pad_b = pad32(c0);                       // conv_b: K = cin_pad_b, N = cin
-      in_n1.wb = taps_in_n(logical(wi, c0, ic, true), ic, c0, nin);
+      taps_in_n(logical(wi, c0, ic, true), ic, c0, nin, &in_n1.wb, &in_n1.wb_alt);
       out_n1.ntaps = 1; out_n1.cin = cf; out_n1.cin_pad = pad32(cf); out_n1.cout = nout; out_n1.bias = nullptr;   // (the bias is added by tap_gather_nchw)
-      out_n1.wf = taps_in_n(logical(wo, oc, cf, false), oc, cf, nout);
+      taps_in_n(logical(wo, oc, cf, false), oc, cf, nout, &out_n1.wf, &out_n1.wf_alt);
       out_k1.ntaps = 1; out_k1.cin = cf; out_k1.cout = 9 * oc; out_k1.cin_pad_b = pad32(9 * oc);
-      out_k1.wb = taps_in_k(logical(wo, oc, cf, true), cf, oc);
+      taps_in_k(logical(wo, oc, cf, true), cf, oc, &out_k1.wb, &out_k1.wb_alt);
       tapfold = true;
     }
   }
-  if (!rc && cdt == DT_F32X3) {
+  if (!rc && is_x3(cdt)) {
     const unsigned zero = 0;
     x3_amax = (unsigned*)upload(&zero, sizeof(zero));
     x3_sat = (unsigned*)upload(&zero, sizeof(zero));
@@ -336,7 +347,9 @@ static const int g_x3_tf2 = [] { const char* e = getenv("KDIP_X3_TF2"); return e
 namespace {
 struct Ctx {
   UNet* u; hipStream_t st; bool dry; DType dt; size_t es;
-  DType cdt() const { return u->cdt; }
+  DType cdt() const { return u->ccdt(); }
+  const void* wf(const ConvW& w) const { return (u->has_alt && u->x3_alt) ? w.wf_alt : w.wf; }
+  const void* wb(const ConvW& w) const { return (u->has_alt && u->x3_alt) ? w.wb_alt : w.wb; }
 };
 
 double* new_sums(Ctx& c, int B) { return (double*)c.u->zeros.alloc(sizeof(double) * B * 64); }
@@ -498,7 +511,7 @@ int conv_f(Ctx& c, const ConvW& w, const void* x, long ldx, int B, int H, int W,
   }
   stt.sk_det = c.u->det ? 1 : 0;
   stt.x3_sat = c.u->x3_sat;
-  RUN(conv_forward(c.st, c.cdt(), w.ntaps, x, ldx, B, H, W, w.cin_pad, w.wf, w.bias, w.cout, y, ldy, res, ldr, out_f32, 1.f, w.cin,
+  RUN(conv_forward(c.st, c.cdt(), w.ntaps, x, ldx, B, H, W, w.cin_pad, c.wf(w), w.bias, w.cout, y, ldy, res, ldr, out_f32, 1.f, w.cin,
                    (stt.mode || in_ups || res_ups || tf_coef || stt.sk_det || stt.x3_sat) ? &stt : nullptr, c.u->sk_ws, c.u->sk_ws_floats));
   return KDIP_OK;
 }
@@ -562,7 +575,7 @@ int conv_b(Ctx& c, const ConvW& w, const void* g, long ldg, int B, int H, int W,
   }
   stt.sk_det = c.u->det ? 1 : 0;
   stt.x3_sat = c.u->x3_sat;
-  RUN(conv_forward(c.st, c.cdt(), w.ntaps, g, ldg, B, H, W, w.cin_pad_b, w.wb, nullptr, w.cin, y, ldy, res, ldr, out_f32, 1.f, w.cout,
+  RUN(conv_forward(c.st, c.cdt(), w.ntaps, g, ldg, B, H, W, w.cin_pad_b, c.wb(w), nullptr, w.cin, y, ldy, res, ldr, out_f32, 1.f, w.cout,
                    (stt.mode || stt.x3_amax || stt.sk_det || stt.tf_coef) ? &stt : nullptr, c.u->sk_ws, c.u->sk_ws_floats));
   return KDIP_OK;
 }
@@ -850,7 +863,7 @@ static int res_backward(Ctx& c, Layer& L, const void* G, long ldG, void** gxp, c
   void* g3 = u->scratch.alloc(es * B * HWo * L.cout);
   double* sums2 = nullptr;     // GN2-backward sums accumulated by the dgrad epilogue when the shape allows
   int g3_dz = 0;               // g3 holds dz (the dgrad epilogue already applied silu') instead of dy
-  const bool fbx_ok = g_x3_tf2 && c.cdt() == DT_F32X3 && conv_tf_eligible(c.cdt(), 9, Ho, Wo, L.c1.cin_pad_b) && !gn_small_eligible(c.dt, HWo, L.cout);
+  const bool fbx_ok = g_x3_tf2 && is_x3(c.cdt()) && conv_tf_eligible(c.cdt(), 9, Ho, Wo, L.c1.cin_pad_b) && !gn_small_eligible(c.dt, HWo, L.cout);
   CK(conv_b(c, L.c2, G, ldG, B, Ho, Wo, g3, L.cout, nullptr, 0, 0, L.sv.h2, L.cout, L.sv.coef2, L.sv.mr2, 1, &sums2, nullptr, nullptr, &g3_dz, nullptr, nullptr, 0, fbx_ok));
   // conv1 dgrad -> grad wrt (resampled) h1.  Second-generation kernel + fused sums: the GN2 backward apply
   // (gh2 = a*dz - (k0 + k1*h2)) happens inside the dgrad conv's input staging; gh2 is never written.

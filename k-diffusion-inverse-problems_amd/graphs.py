@@ -40,6 +40,7 @@ class GraphedDenoiser:
         self.cg_trips = {}
         self._cg_floor = {}            # key -> trips an earlier re-capture needed (kept across graph invalidations)
         self.cg_redone = 0             # fixed-trip replays that were not converged and were redone eagerly
+        self.x3_redone = 0             # dtype "f16x3": replays whose fp16-window flag came up and were redone eagerly (bf16-headed)
         self._graphs = {}          # (sigma, shape) -> (graph, static_x, static_out)
         self.replays = 0
         self.eager_calls = 0
@@ -133,6 +134,14 @@ class GraphedDenoiser:
         sx.copy_(x)
         g.replay()
         self.replays += 1
+        # dtype "f16x3": a captured call cannot poll its fp16-window flag (no host reads under capture), so the replay is polled here
+        # -- one stream synchronisation, as for the fixed-trip CG counter -- and a flagged call is redone eagerly, where
+        # UNetModel.guarded() falls back to the bf16-headed arithmetic
+        model = getattr(self.den, "inner_model", None) or getattr(getattr(self.den, "denoiser", None), "inner_model", None)
+        if getattr(model, "x3_guard", False) and getattr(model, "dtype", None) == "f16x3" and (model.x3_saturated() & 1):
+            self.x3_redone += 1
+            self.eager_calls += 1
+            return self.den(x, sigma)
         if key in self.cg_trips and self.cg_check == "each" and self.cg_unconverged() > 0:
             # the fixed trip count taken from the warm-up input was too small for THIS input: the reference iterates to tolerance or
             # maxiter and warns (condition.py:343-347), so do the same -- adaptive solve now, more trips for the next replay

@@ -85,6 +85,12 @@ class UNetModel:
         self._h = h
         self._finalized = False
         self.has_out_cov = False
+        # dtype "f16x3": the fp16-headed split arithmetic is exact only while every conv operand stays inside the fp16 window; the library
+        # raises a flag otherwise and this wrapper redoes the flagged call in the bf16-headed arithmetic (the handle carries both weight
+        # encodings).  x3_guard = False leaves the polling to the caller (x3_saturated(), e.g. under hipGraph capture: graphs.py).
+        self.x3_guard = dtype == "f16x3"
+        self.x3_fallbacks = 0          # calls redone bf16-headed
+        self.x3_degraded = 0           # ... of which the bf16-headed pass itself lost tail precision on some operand (bit 0 of the flag)
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -121,19 +127,38 @@ class UNetModel:
         cov = torch.empty(B, 6, self.image_size, self.image_size, device=x.device) if want_cov else None
         feat = torch.empty(B, self.channel_mult[0] * self.model_channels, self.image_size, self.image_size,
                            device=x.device) if want_feature else None
-        L.check(self.lib.kdip_unet_forward(self._h, L.stream(), L.ptr(x), L.ptr(t), B, float(in_scale), L.ptr(out),
-                                           L.ptr(cov), L.ptr(feat)))
+        self.guarded(lambda: L.check(self.lib.kdip_unet_forward(self._h, L.stream(), L.ptr(x), L.ptr(t), B, float(in_scale), L.ptr(out),
+                                                                L.ptr(cov), L.ptr(feat))))
         return out, cov, feat
 
+    def guard_active(self):
+        return self.x3_guard and self.dtype == "f16x3" and not torch.cuda.is_current_stream_capturing()
+
+    def guarded(self, call):
+        """Run `call` (library launches on the current stream that write their results in place).  dtype "f16x3": poll the fp16-window
+        flag afterwards (one stream synchronisation) and, if some operand left the window, run `call` again in the bf16-headed
+        arithmetic (kdip_unet_x3_head) -- the result a "bf16x3" handle would have produced."""
+        call()
+        if not self.guard_active():
+            return
+        if self.x3_saturated() & 1:
+            self.x3_fallbacks += 1
+            L.check(min(self.lib.kdip_unet_x3_head(self._h, 1), 0))
+            try:
+                call()
+                self.x3_degraded += self.x3_saturated() & 1      # (also clears the flag for the next fp16-headed call)
+            finally:
+                L.check(min(self.lib.kdip_unet_x3_head(self._h, 0), 0))
+
     def set_x3_window(self, mode):
-        """dtype "bf16x3" only: "vjp" (default) = one fp16-window scale per VJP from max |cotangent|; "launch" = every dgrad conv scales
+        """dtype "bf16x3" / "f16x3" only: "vjp" (default) = one fp16-window scale per VJP from max |cotangent|; "launch" = every dgrad conv scales
         by a sampled max of its own input (robust to networks with very large backward gains, +2 % per call)."""
         if mode not in ("vjp", "launch"):
             raise ValueError("mode must be 'vjp' or 'launch'")
         L.check(self.lib.kdip_unet_x3_window(self._h, 1 if mode == "launch" else 0))
 
     def x3_saturated(self, reset=True):
-        """dtype "bf16x3" only: flags of operands that left the fp16 window of the split-precision convs since the last reset (bit 0:
+        """dtype "bf16x3" / "f16x3" only: flags of operands that left the fp16 window of the split-precision convs since the last reset (bit 0:
         an activation / gradient operand in some launch, bit 1: a weight at pack time); 0 = every conv product carried its full
         precision.  One stream synchronisation."""
         import ctypes as C
@@ -158,7 +183,7 @@ class UNetModel:
         cot = cot.contiguous()
         B = cot.shape[0]
         gx = torch.empty(B, self.in_channels, self.image_size, self.image_size, device=cot.device)
-        L.check(self.lib.kdip_unet_vjp(self._h, L.stream(), L.ptr(cot), B, L.ptr(gx)))   # the library rejects B != batch of the last forward
+        self.guarded(lambda: L.check(self.lib.kdip_unet_vjp(self._h, L.stream(), L.ptr(cot), B, L.ptr(gx))))   # the library rejects B != batch of the last forward
         return gx
 
     def forward(self, x, timesteps, y=None, return_feature=False):

@@ -37,4 +37,13 @@ def test_config_runs_at_per_gpu_batch(wl):
         assert torch.equal(a, b), (wl, s, float((a - b).abs().max()))                 # deterministic parity mode: bitwise repeatable
     u = bench.unet_of(den)
     assert u.x3_saturated() == 0
+    if wl == "cfg1":      # the opt-in fp16-headed split on the benchmarked config at its batch: in-window (no call redone bf16-headed), repeatable
+        del den
+        torch.cuda.empty_cache()
+        denh, _, _, _ = bench.build_problem(WL, "f16x3", dev, B, sd, D, seed=0)
+        s = float(sig[10])
+        x = (x0 + s * noise).contiguous()
+        a = denh(x, torch.full((B,), s, device=dev)).clone()
+        b = denh(x, torch.full((B,), s, device=dev)).clone()
+        assert torch.isfinite(a).all() and torch.equal(a, b) and bench.unet_of(denh).x3_fallbacks == 0
     print(f"\n{wl} B={B} bf16x3: UNet workspace {u.workspace_bytes(B) / 1e9:.2f} GB, torch peak {torch.cuda.max_memory_allocated() / 1e9:.2f} GB ({WL['label'].split(':')[0]})")

@@ -18,7 +18,7 @@ def _ffhq(dt):
     return m
 
 
-@pytest.mark.parametrize("dt", ["f32", "bf16x3"])
+@pytest.mark.parametrize("dt", ["f32", "bf16x3", "f16x3"])
 def test_unet_forward_vjp_bitwise_reproducible(dt):
     """FFHQ architecture at 256 x 256, batch 3 (not a power of two: ragged tile / chunk counts): forward + input-VJP three times ->
     identical bits.  With the fixed-order reductions switched off (the bf16 mode's atomics) the same call agrees to fp32 rounding,

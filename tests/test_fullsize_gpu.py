@@ -76,7 +76,7 @@ def test_ffhq_type1_convert_fullsize(sigma_v):
     measd = (meas[0].cuda(), meas[1].cuda())
     oden = ocond.GuidedDenoiser(sd, ocfg, oop, meas, "I", x0_cov_type="convert")
     errs, ref32 = {}, None
-    for dtype in ("f32", "bf16x3"):
+    for dtype in ("f32", "bf16x3", "f16x3"):
         if dtype != "f32":
             del m, hm
             torch.cuda.empty_cache()
@@ -88,7 +88,8 @@ def test_ffhq_type1_convert_fullsize(sigma_v):
         print(f"\nFFHQ configs[1] full-size sigma={sigma_v} {dtype}: max-abs {errs[dtype]:.2e}; borderline clamp pixels {flips}")
         if dtype == "f32":
             ref32 = ref
-    assert errs["f32"] < 2e-4 and errs["bf16x3"] < 2e-4, errs          # measured <= 7.6e-5
+    assert errs["f32"] < 2e-4 and errs["bf16x3"] < 2e-4 and errs["f16x3"] < 2e-4, errs          # measured <= 7.6e-5
+    assert m.x3_fallbacks == 0                       # (the last handle is the f16x3 one: its own arithmetic produced the result)
     del m, hm
     torch.cuda.empty_cache()
     m2 = ku.UNetModel(dtype="bf16", **ku.FFHQ_CONFIG); m2.load_state_dict(sd)

@@ -2,7 +2,8 @@
 channel_mult (1, 2), batch 12 -- large enough that the production bf16 path routes its 64 x 64 convs through csrc/conv3.hip
 (GroupNorm + SiLU staging `gnf`, fused forward / backward statistics `s1` / `s2`, GroupNorm-backward staging `gnb`, coefficient
 fold), so those kernels are compared with REFERENCE output (guided_diffusion/unet.py:636-668 forward, its autograd input-VJP, and
-condition/condition.py:83-131 guided calls), not only with the oracle.  f32 and bf16x3 run the same fixture at the f32 bounds."""
+condition/condition.py:83-131 guided calls), not only with the oracle.  f32, bf16x3 and f16x3 (the opt-in fp16-headed split: no call of
+this fixture may fall back to the bf16-headed arithmetic) run the same fixture at the f32 bounds."""
 import csv
 import ctypes as C
 import os
@@ -29,7 +30,7 @@ def mid():
     cfg = ounet.UNetConfig(**MID)
     sd = ounet.init_state_dict(cfg, seed=0)
     models = {}
-    for dt in ("f32", "bf16x3", "bf16"):
+    for dt in ("f32", "bf16x3", "f16x3", "bf16"):
         m = ku.UNetModel(dtype=dt, **MID)
         m.load_state_dict(sd)
         models[dt] = m
@@ -53,7 +54,7 @@ def _profiled_tags(fn):
 
 
 # max |err| / max |ref| of the UNet output and of the input-VJP per arithmetic mode: f32 / bf16x3 the exact-mode bound, bf16 3 x measured
-UNET_BOUNDS = {"f32": (1e-4, 1e-4), "bf16x3": (1e-4, 1e-4), "bf16": (None, None)}
+UNET_BOUNDS = {"f32": (1e-4, 1e-4), "bf16x3": (1e-4, 1e-4), "f16x3": (1e-4, 1e-4), "bf16": (None, None)}
 
 
 def test_unet_mid_forward_vjp_vs_reference(gold, mid):
@@ -74,6 +75,8 @@ def test_unet_mid_forward_vjp_vs_reference(gold, mid):
             assert eo < 4e-2 and ev < 6e-2, (eo, ev)          # 3 x measured (1.4e-2 / 2.0e-2)
         else:
             assert eo < UNET_BOUNDS[dt][0] and ev < UNET_BOUNDS[dt][1], (dt, eo, ev)
+        if dt == "f16x3":
+            assert m.x3_fallbacks == 0      # in-window data: the fp16-headed arithmetic itself produced these numbers
 
 
 @pytest.mark.parametrize("sigma_v", [1.5, 0.12])

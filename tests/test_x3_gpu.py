@@ -180,3 +180,56 @@ def test_x3_optin_backward_fusions_match_reference(env):
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_mid_gpu.py"), "-x", "-q", "-m", "gpu"],
                        env=dict(os.environ, **env), capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, (env, r.stdout[-2000:], r.stderr[-1000:])
+
+
+def test_f16x3_conv_error_ladder():
+    """The opt-in fp16-headed split (dtype "f16x3": three fp16 MFMAs per product, 11 + 11-bit operands; csrc/conv.hip Mma<f32h3_t>) against an
+    fp64 conv on data inside its window: at least the accuracy of the bf16-headed split (measured 4.7e-7 vs 7e-7), forward and input-gradient
+    (the dgrad operand is scaled by max |cotangent| as in the UNet's VJP), 3x3 and 1x1."""
+    import kdip_amd._lib as L
+    L.require_gpu()
+    g = torch.Generator().manual_seed(5)
+    for (B, Cin, Cout, H, W, nt) in ((2, 128, 128, 32, 32, 9), (1, 256, 64, 16, 16, 9), (2, 192, 128, 16, 16, 1)):
+        k = 3 if nt == 9 else 1
+        w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * nt) ** 0.5
+        x = torch.randn(B, Cin, H, W, generator=g)
+        ref = F.conv2d(x.double(), w.double(), None, padding=k // 2)
+        e3 = float((_conv(L, 3, x, w, None, nt).double() - ref).abs().max() / ref.abs().max())
+        e2 = float((_conv(L, 2, x, w, None, nt).double() - ref).abs().max() / ref.abs().max())
+        print(f"\nf16x3 conv {Cin}->{Cout} @{H} taps {nt}: max|err|/max|ref| f16x3 {e3:.2e}  (bf16x3 {e2:.2e})")
+        assert e3 < 1.2e-6, (Cin, Cout, nt, e3)
+    for scale in (1e-3, 1.0, 1e4):                    # gradient operand: no natural scale, window follows max |g|
+        gch = torch.randn(2, 128, 32, 32, generator=g) * scale
+        w = torch.randn(128, 96, 3, 3, generator=g) / (96 * 9) ** 0.5
+        ref = F.conv_transpose2d(gch.double(), w.double(), None, padding=1)
+        y = _conv(L, 3, gch, w, None, 9, transpose_flip=1)
+        e = float((y.double() - ref).abs().max() / ref.abs().max())
+        print(f"f16x3 dgrad, cotangent scale {scale:g}: max|err|/max|ref| {e:.2e}")
+        assert e < 1.2e-6, (scale, e)
+
+
+def test_f16x3_out_of_window_call_is_redone_bf16_headed():
+    """dtype "f16x3" is exact-grade only inside the fp16 window of its head planes.  An operand beyond +-65504 (after the power-of-two scaling)
+    raises bit 0 of kdip_unet_x3_saturated; UNetModel.guarded() polls it after every forward / VJP / fused guided call and redoes the
+    flagged call on the bf16-headed weights the handle carries: the result is BITWISE the one a "bf16x3" handle produces, and the next
+    in-window call runs fp16-headed again."""
+    import kdip_amd.unet as ku
+    from oracle import unet as ounet
+    cfg = ounet.UNetConfig(**ounet.TINY)
+    sd = ounet.init_state_dict(cfg, seed=0)
+    kw = dict(image_size=64, model_channels=32, num_res_blocks=1, attention_resolutions="32", channel_mult=(1, 2))
+    mb = ku.UNetModel(dtype="bf16x3", **kw).load_state_dict(sd)
+    mh = ku.UNetModel(dtype="f16x3", **kw).load_state_dict(sd)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 3, 64, 64, generator=g).cuda()
+    t = torch.tensor([100.0, 700.0]).cuda()
+    o1 = mh.forward_raw(x, t)[0].clone()
+    assert mh.x3_fallbacks == 0 and not torch.equal(o1, mb.forward_raw(x, t)[0])      # a different arithmetic, inside its window
+    ob = mb.forward_raw(x * 1e7, t)[0].clone()
+    oh = mh.forward_raw(x * 1e7, t)[0].clone()
+    assert mh.x3_fallbacks == 1 and torch.isfinite(oh).all() and torch.equal(oh, ob)
+    o2 = mh.forward_raw(x, t)[0]
+    assert mh.x3_fallbacks == 1 and torch.equal(o1, o2)
+    mh.x3_guard = False                               # the caller polls itself (what graphs.py does around a replay)
+    mh.forward_raw(x * 1e7, t)
+    assert mh.x3_saturated() & 1 and mh.x3_fallbacks == 1
