@@ -91,7 +91,10 @@ int kdip_unet_x3_window(kdip_unet* u, int per_launch);
 /* (no reference counterpart) KDIP_BF16X3 handles: *flags_host = bit 0: since the last reset some conv launch staged an activation /
  * gradient operand outside the fp16 window of its tail planes (|a * 2^sa| > 65504: that product fell back towards bf16 accuracy);
  * bit 1: a weight of this handle was outside the window when it was packed (|w| > 255.9).  0 = every product of every conv carried its
- * full split precision.  Synchronises `stream`. */
+ * full split precision.  KDIP_F16X3 handles also: bit 2: some conv launch's whole operand tensor (non-zero) sat below 2^-12 of its scale
+ * reference, under the fp16 head's normal range (the low side of the window; found per launch, checked at the end of each forward / VJP);
+ * bit 3: a weight tensor of the handle sits under that range, the handle runs bf16-headed throughout.  Bits 0 and 2 = "redo this call
+ * with kdip_unet_x3_head(u, 1)".  Synchronises `stream`. */
 int kdip_unet_x3_saturated(kdip_unet* u, void* stream, int reset, int* flags_host);
 /* (no reference counterpart) KDIP_F16X3 handles: bf16_head = 1 -> the following kdip_unet_forward / kdip_unet_vjp / kdip_guided_call_v1 run in the
  * KDIP_BF16X3 arithmetic on the bf16-headed weights the handle carries (same workspace plan, same activation stash: a VJP may be redone

@@ -47,6 +47,10 @@ int kdip_debug_conv3_timing(void* dev_buf);
 /* Test / A-B aid: 1 (default) = the large-map bf16 convs compute their GroupNorm staging coefficients from the statistics themselves
  * (no gn_coef / gn_merge_stats / gn_bwd_coef launches between two convs); 0 = separate coefficient kernels.  Results are bit-identical. */
 int kdip_debug_gn_fold(int on);
+/* Diagnostic (KDIP_F16X3 handles): the per-launch peak words of the LAST fp16-headed pass (forward or VJP) -- largest |scaled operand| each conv
+ * launch staged, in launch order; *n_host = number of launches (<= max copied).  Synchronises `stream`.  tools/f16x3_check.py prints the
+ * distribution: how far real workloads sit from the low side of the fp16 window. */
+int kdip_debug_x3_peaks(kdip_unet* u, void* stream, float* peaks_host, int max, int* n_host);
 
 #ifdef __cplusplus
 }

@@ -325,6 +325,7 @@ class ConditionOpenAIDenoiser(ConditionDenoiser):
         hat = torch.empty_like(x)
         iters, info = (C.c_int * B)(), (C.c_int * B)()
         # (dtype "f16x3": the whole call is redone bf16-headed when an operand of one of its convs left the fp16 window -- UNetModel.guarded)
+        self.inner_model.before_forward()
         self.inner_model.guarded(lambda: L.check(self.lib.kdip_guided_call_v1(self.inner_model._h, op._h, L.stream(), L.ptr(x), L.ptr(self._fused_t), L.ptr(y), B, t7,
                                                                               float(s), v, int(tensor_var), L.ptr(self._fused_ws), L.ptr(hat), iters, info)))
         op.cg_iters, op.cg_info = list(iters), list(info)

@@ -126,7 +126,17 @@ int kdip_unet_x3_saturated(kdip_unet* u, void* stream, int reset, int* flags_hos
   KDIP_HIP_CHECK(hipMemcpyAsync(&w, u->u.x3_sat, sizeof(w), hipMemcpyDeviceToHost, ST(stream)));
   if (reset) KDIP_HIP_CHECK(hipMemsetAsync(u->u.x3_sat, 0, sizeof(unsigned), ST(stream)));
   KDIP_HIP_CHECK(hipStreamSynchronize(ST(stream)));
-  *flags_host = (int)(w & 1u) | (u->u.x3_weight_sat > 0 ? 2 : 0);
+  *flags_host = (int)(w & 5u) | (u->u.x3_weight_sat > 0 ? 2 : 0) | (u->u.x3_force_alt ? 8 : 0);
+  return KDIP_OK;
+}
+int kdip_debug_x3_peaks(kdip_unet* u, void* stream, float* peaks_host, int max, int* n_host) {
+  KDIP_REQUIRE(u && peaks_host && n_host, "null argument");
+  const int n = u->u.x3_peaks ? std::min(std::min(u->u.x3_npeaks, (int)UNet::X3_MAX_PEAKS), max) : 0;
+  *n_host = n;
+  if (n > 0) {
+    KDIP_HIP_CHECK(hipMemcpyAsync(peaks_host, u->u.x3_peaks, sizeof(float) * n, hipMemcpyDeviceToHost, ST(stream)));
+    KDIP_HIP_CHECK(hipStreamSynchronize(ST(stream)));
+  }
   return KDIP_OK;
 }
 int kdip_unet_x3_head(kdip_unet* u, int bf16_head) {

@@ -176,6 +176,8 @@ struct ConvParams {
   float* det_slab; size_t det_slab_bytes;   // deterministic modes (det.h): fused statistics go block by block into det_slab [B][tiles per image][n-blocks][BN/4][2] and are
                                   // added in slot order by conv_stats_finish_kernel; split-K partials go to per-split slabs of sk_ws (sk_det)
   int sk_det;
+  int x3_lds_peak_off;            // ... byte offset, behind everything else in the block's dynamic LDS, of its four per-wave running maxima (a register held across the K loop costs a spill)
+  unsigned* x3_lowpeak;           // fp16-headed split: optional device word <- atomic max of the bits of the largest |scaled A operand| of the launch (ConvStats::x3_lowpeak)
   unsigned* x3_sat;               // split precision: optional device word, bit 0 is set when an A operand (after its power-of-two scaling) leaves the fp16 window
                                   // (|a| > 65504: its fp16 tail planes saturate and the product degrades towards the bf16 head's accuracy)
   const unsigned* x3_amax;        // split precision: optional device word = bits of max |x| of the input's tensor family (sets the fp16 window of the A operand)
@@ -794,6 +796,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (X3Tag<T>::is) ? (MT * NT ==
   // (instantiations that never run persistently get a compile-time single trip: no loop-carried state, no hoisting pressure)
   int xj = blockIdx.x >> 3;
   if (xj >= xlen) return;
+  if constexpr (X3Tag<T>::mode == 2) {
+    if (p.x3_lowpeak) ((unsigned*)(smem + p.x3_lds_peak_off))[threadIdx.x] = 0u;      // own word of each thread: no barrier needed
+  }
   do {
   const int bid = xstart + xj;
   const int kdip_tile = bid; (void)kdip_tile;
@@ -1008,6 +1013,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (X3Tag<T>::is) ? (MT * NT ==
     }
     if constexpr (X3M) {
       if (x3_peak > 65504.f && p.x3_sat) atomicOr(p.x3_sat, 1u);      // (rare branch: nothing is issued while every operand is inside the window)
+      if constexpr (XMODE == 2) {                       // the thread's running maximum lives in its own LDS word: one no-return ds_max_u32 per chunk, conflict-free,
+        if (p.x3_lowpeak) atomicMax((unsigned*)(smem + p.x3_lds_peak_off) + tid, __float_as_uint(x3_peak));      // nothing waits for it (a register held across the K loop costs a spill, a per-chunk wave reduction 6 LDS round trips)
+      }
     }
   };
 
@@ -1134,6 +1142,21 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (X3Tag<T>::is) ? (MT * NT ==
   }
   have_patch = pref;
   pb = (pb + nchunks - c_begin) & 1;
+  if constexpr (XMODE == 2) {
+    // the launch's largest staged operand: one atomic max per wave, skipped once the word already holds a larger value (positive floats order like their bits)
+    // (all slot updates are behind the last chunk's barrier) wave 0 folds the block's slots and issues ONE no-return atomic max per block: nothing
+    // waits for global memory here (a load of the word to skip the atomic put an L2 round trip in front of every block's epilogue: +4 % per step)
+    // Launches of >= 512 tiles report every 8th block: 4 096 same-address atomics per launch measured +1.8 % per step.  A sampled maximum can
+    // only be SMALLER than the true one: the low-side flag stays conservative (a spurious redo, never a missed one).
+    if (p.x3_lowpeak && wave == 0 && (ntiles < 512 || (bid & 7) == 0)) {
+      const unsigned* sl = (const unsigned*)(smem + p.x3_lds_peak_off);
+      unsigned m = sl[lane];
+#pragma unroll
+      for (int w = 1; w < WAVES_M * WAVES_N; ++w) m = m > sl[w * 64 + lane] ? m : sl[w * 64 + lane];
+      m = __float_as_uint(wave_max(__uint_as_float(m)));
+      if (lane == 0) atomicMax(p.x3_lowpeak, m);
+    }
+  }
 
   KDIP_STAMP(2);
   // ---- epilogue: alpha, bias, residual, cast.
@@ -1432,6 +1455,12 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
       return set_error(KDIP_ERR_UNSUPPORTED, "conv: GroupNorm-backward epilogue (mode 3) needs an fp32-storage 1x1 conv, one image per tile, Cout %% %d == 0 and 16-byte aligned operands", BN);
   } else if (p.st_mode && !(p.vec_epilogue && TB == 1 && p.Cout % 32 == 0 && ((p.Cout >> 5) % 4) == 0))
     return set_error(KDIP_ERR_UNSUPPORTED, "conv: fused GroupNorm statistics not available for this shape");
+  p.x3_lds_peak_off = 0;
+  if (X3Tag<T>::mode == 2 && p.x3_lowpeak) {      // one word per thread behind everything else
+    lds = (lds + 15) & ~(size_t)15;
+    p.x3_lds_peak_off = (int)lds;
+    lds += 4 * (WAVES_M * WAVES_N * 64);
+  }
   int nblkN = cdiv(p.ntilesN * 32, BN);
   long grid = (long)p.mtiles * nblkN;
   constexpr bool TF_OK = X3Tag<T>::is && NTAPS == 9 && SUBS == 1;
@@ -1596,6 +1625,7 @@ int conv_forward(hipStream_t st, DType dt, int ntaps, const void* x, long ldx, i
   p.in_ups = stt ? stt->in_ups : 0; p.res_ups = stt ? stt->res_ups : 0;
   p.x3_amax = stt ? stt->x3_amax : nullptr;
   p.x3_sat = stt ? stt->x3_sat : nullptr;
+  p.x3_lowpeak = (stt && dt == DT_F32H3) ? stt->x3_lowpeak : nullptr;
   const DetWs* det = stt ? stt->det : nullptr;
   p.det_slab = det ? (float*)det->slab : nullptr; p.det_slab_bytes = det ? det->slab_bytes : 0;
   p.sk_det = stt ? stt->sk_det : 0;
@@ -1670,6 +1700,21 @@ static float f16_bits_to_f32(uint16_t h) {      // exact
 // one handle per rank thread) cannot set bit 1 of kdip_unet_x3_saturated on a handle whose own weights were in range.
 static thread_local long t_x3_weight_sat = 0;
 long x3_weight_saturations() { return t_x3_weight_sat; }
+static thread_local long t_x3_weight_low = 0;
+long x3_weight_subwindow() { return t_x3_weight_low; }
+__global__ void x3_lowpeak_check_kernel(const unsigned* __restrict__ peaks, int n, unsigned* __restrict__ flag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const unsigned v = peaks[i];
+    if (v != 0u && v < 0x39800000u) atomicOr(flag, 4u);      // 0x39800000 = 2^-12: non-zero operand tensor entirely under the fp16 head's normal range
+  }
+}
+int x3_lowpeak_check(hipStream_t st, const unsigned* peaks, int n, unsigned* flag) {
+  if (n <= 0) return KDIP_OK;
+  hipLaunchKernelGGL(x3_lowpeak_check_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, peaks, n, flag);
+  KDIP_LAUNCH_CHECK();
+  return KDIP_OK;
+}
 
 void pack_conv_weight(DType dt, const float* w, int Cout, int Cin, int ntaps, int transpose_flip, int Cin_pad_out,
                       void* out) {
@@ -1685,6 +1730,9 @@ void pack_conv_weight(DType dt, const float* w, int Cout, int Cin, int ntaps, in
   if (is_x3(dt)) {
     bf16_t* o = (bf16_t*)out;
     long idx = 0;
+    float wmax = 0.f;
+    for (long i = 0; i < (long)Cout * Cin * ntaps; ++i) wmax = fmaxf(wmax, fabsf(w[i]));
+    if (dt == DT_F32H3 && wmax > 0.f && wmax * X3_S < 0.000244140625f) ++t_x3_weight_low;
     for (int tap = 0; tap < ntaps; ++tap)
       for (int ks = 0; ks < ksteps; ++ks)
         for (int nt = 0; nt < ntiles; ++nt, idx += 2 * 64 * 8)

@@ -22,6 +22,10 @@ struct ConvStats {
   // cotangent), or null for inputs of O(1) scale (forward activations): sets the fp16 window of the A operand (conv.hip, Mma<f32x3_t>)
   const unsigned* x3_amax = nullptr;
   unsigned* x3_sat = nullptr;      // ... and a device word whose bit 0 the kernel sets when a scaled operand leaves that window (|a| > 65504)
+  // fp16-headed split (DT_F32H3) only: device word that receives (atomic max) the bits of the largest |scaled operand| this LAUNCH staged.  The
+  // fp16 head loses its relative precision below 2^-14: a launch whose whole operand tensor sits below the window is found by
+  // x3_lowpeak_check and flagged (bit 2 of x3_sat) -- the other side of the window watch
+  unsigned* x3_lowpeak = nullptr;
   // split-precision 3x3 convs on maps with >= 128 pixels: the input is a GroupNorm INPUT and silu?(a*x + b), (a, b) = tf_coef [B][Cin][2]
   // (gn_coef), is applied while the patch is staged -- the activated tensor never exists in HBM (as Conv3Fuse::tf 1 does for bf16)
   const float* tf_coef = nullptr; int tf_silu = 0;
@@ -57,6 +61,8 @@ int conv_forward(hipStream_t st, DType dt, int ntaps, const void* x, long ldx, i
 // sk_ws: optional fp32 split-K workspace of sk_ws_floats floats, all zero on entry and on return; when given, under-filled
 // launches (small-spatial layers) split their K range over blockIdx.y and reduce through it
 size_t packed_weight_bytes(DType dt, int ntaps, int Cin_pad, int Cout);
+long x3_weight_subwindow();         // ... DT_F32H3: weight TENSORS packed so far whose largest scaled magnitude is non-zero and below 2^-12 (under the fp16 head's normal range)
+int x3_lowpeak_check(hipStream_t st, const unsigned* peaks, int n, unsigned* flag);      // flag |= 4 when any launch's peak word is non-zero and below 2^-12
 long x3_weight_saturations();       // running count (of the calling host thread) of DT_F32X3 weights packed so far whose scaled value left the fp16 window (|w| > 255.9)
 int conv_debug_timing(void* buf, int H, int cin, int cout, int st_mode);   // -DKDIP_TIMING=1 diagnostic builds only
 void pack_conv_weight(DType dt, const float* w, int Cout, int Cin, int ntaps, int transpose_flip, int Cin_pad_out,

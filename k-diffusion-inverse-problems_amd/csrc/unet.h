@@ -70,7 +70,11 @@ struct UNet {
   // next forward / VJP run on them (kdip_unet_x3_head): how a caller redoes a call whose saturation flag came up.  Same tiles, same
   // workspace plan, same stash: only the conv arithmetic changes.
   bool has_alt = false, x3_alt = false;
-  DType ccdt() const { return (has_alt && x3_alt) ? DT_F32X3 : cdt; }
+  bool x3_force_alt = false;         // a weight tensor of the handle sits under the fp16 head's normal range: the handle runs bf16-headed throughout
+  bool alt() const { return has_alt && (x3_alt || x3_force_alt); }
+  DType ccdt() const { return alt() ? DT_F32X3 : cdt; }
+  unsigned* x3_peaks = nullptr; int x3_npeaks = 0;      // fp16-headed passes: one word per conv launch (zeros arena) for the largest staged operand (x3_lowpeak_check at the end of the pass)
+  static constexpr int X3_MAX_PEAKS = 1024;
   int device = 0;
   std::vector<std::vector<Layer>> inp, out;
   std::vector<Layer> mid;

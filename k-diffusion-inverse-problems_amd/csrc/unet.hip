@@ -174,7 +174,7 @@ int UNet::finalize() {
   KDIP_REQUIRE(!finalized, "unet already finalized");
   KDIP_HIP_CHECK(hipSetDevice(device));
   int rc = KDIP_OK;
-  const long x3_w0 = x3_weight_saturations();
+  const long x3_w0 = x3_weight_saturations(), x3_l0 = x3_weight_subwindow();
   auto need = [&](const std::string& k, long numel) -> const float* {
     auto it = raw.find(k);
     if (it == raw.end()) { rc = set_error(KDIP_ERR_STATE, "missing parameter '%s'", k.c_str()); return nullptr; }
@@ -322,6 +322,7 @@ int UNet::finalize() {
   }
   if (rc) return rc;
   x3_weight_sat = x3_weight_saturations() - x3_w0;      // (thread-local counter: exactly this handle's weights)
+  x3_force_alt = has_alt && x3_weight_subwindow() - x3_l0 > 0;
   raw.clear();
   finalized = true;
   return KDIP_OK;
@@ -348,8 +349,14 @@ namespace {
 struct Ctx {
   UNet* u; hipStream_t st; bool dry; DType dt; size_t es;
   DType cdt() const { return u->ccdt(); }
-  const void* wf(const ConvW& w) const { return (u->has_alt && u->x3_alt) ? w.wf_alt : w.wf; }
-  const void* wb(const ConvW& w) const { return (u->has_alt && u->x3_alt) ? w.wb_alt : w.wb; }
+  const void* wf(const ConvW& w) const { return u->alt() ? w.wf_alt : w.wf; }
+  const void* wb(const ConvW& w) const { return u->alt() ? w.wb_alt : w.wb; }
+  unsigned* peak_slot() const {      // fp16-headed pass: this launch's word of the low-side window watch
+    if (!u->x3_peaks || u->ccdt() != DT_F32H3) return nullptr;
+    const int i = u->x3_npeaks < UNet::X3_MAX_PEAKS - 1 ? u->x3_npeaks : UNet::X3_MAX_PEAKS - 1;
+    ++u->x3_npeaks;
+    return u->x3_peaks + i;
+  }
 };
 
 double* new_sums(Ctx& c, int B) { return (double*)c.u->zeros.alloc(sizeof(double) * B * 64); }
@@ -511,6 +518,7 @@ int conv_f(Ctx& c, const ConvW& w, const void* x, long ldx, int B, int H, int W,
   }
   stt.sk_det = c.u->det ? 1 : 0;
   stt.x3_sat = c.u->x3_sat;
+  stt.x3_lowpeak = c.peak_slot();
   RUN(conv_forward(c.st, c.cdt(), w.ntaps, x, ldx, B, H, W, w.cin_pad, c.wf(w), w.bias, w.cout, y, ldy, res, ldr, out_f32, 1.f, w.cin,
                    (stt.mode || in_ups || res_ups || tf_coef || stt.sk_det || stt.x3_sat) ? &stt : nullptr, c.u->sk_ws, c.u->sk_ws_floats));
   return KDIP_OK;
@@ -575,6 +583,7 @@ int conv_b(Ctx& c, const ConvW& w, const void* g, long ldg, int B, int H, int W,
   }
   stt.sk_det = c.u->det ? 1 : 0;
   stt.x3_sat = c.u->x3_sat;
+  stt.x3_lowpeak = c.peak_slot();
   RUN(conv_forward(c.st, c.cdt(), w.ntaps, g, ldg, B, H, W, w.cin_pad_b, c.wb(w), nullptr, w.cin, y, ldy, res, ldr, out_f32, 1.f, w.cout,
                    (stt.mode || stt.x3_amax || stt.sk_det || stt.tf_coef) ? &stt : nullptr, c.u->sk_ws, c.u->sk_ws_floats));
   return KDIP_OK;
@@ -757,6 +766,9 @@ int UNet::forward_impl(hipStream_t st, const float* x_nchw, const float* t, int 
       sk_ws = (float*)zeros.alloc(sizeof(float) * sk_ws_floats);
     }
   }
+  // fp16-headed pass: one word per conv launch for the largest operand it staged (cleared with the zeros arena above)
+  x3_peaks = ccdt() == DT_F32H3 ? (unsigned*)zeros.alloc(sizeof(unsigned) * X3_MAX_PEAKS) : nullptr;
+  x3_npeaks = 0;
   int H = cfg.image_size, W = cfg.image_size;
   const int mc = cfg.model_channels, ted = mc * 4;
   // timestep embedding MLP (fp32)
@@ -843,6 +855,7 @@ int UNet::forward_impl(hipStream_t st, const float* x_nchw, const float* t, int 
     RUN(nhwc_to_nchw_f32(st, c32, 32, B, 6, H, W, cov_nchw));
   }
   if (feat_nchw) RUN(nhwc_T_to_nchw_f32(st, dt, h, ldh, B, final_ch, H, W, feat_nchw));
+  if (x3_peaks) RUN(x3_lowpeak_check(st, x3_peaks, std::min(x3_npeaks, (int)X3_MAX_PEAKS), x3_sat));
   zeros_fwd_end = (zeros.off + 255) & ~(size_t)255;
   return KDIP_OK;
 }
@@ -995,6 +1008,8 @@ int UNet::vjp_impl(hipStream_t st, const float* cot_nchw, float* gx_nchw) {
   zeros.off = zeros_fwd_end;
   if (!dry && zeros.cap > zeros_fwd_end)
     KDIP_HIP_CHECK(hipMemsetAsync(zeros.base + zeros_fwd_end, 0, zeros.cap - zeros_fwd_end, st));
+  x3_peaks = ccdt() == DT_F32H3 ? (unsigned*)zeros.alloc(sizeof(unsigned) * X3_MAX_PEAKS) : nullptr;
+  x3_npeaks = 0;
   // cotangent NCHW fp32 [B,out_ch,H,W] -> NHWC T padded to 32 channels
   const int cotw = tapfold ? out_k1.cin_pad_b : 32;
   void* cot = persist.alloc(es * B * HW0 * cotw);
@@ -1054,6 +1069,7 @@ int UNet::vjp_impl(hipStream_t st, const float* cot_nchw, float* gx_nchw) {
     RUN(nhwc_to_nchw_f32(st, gx32, 32, B, cfg.in_channels, H0, W0, gx_nchw));
     }
   }
+  if (x3_peaks) RUN(x3_lowpeak_check(st, x3_peaks, std::min(x3_npeaks, (int)X3_MAX_PEAKS), x3_sat));
   return KDIP_OK;
 }
 

@@ -138,7 +138,7 @@ class GraphedDenoiser:
         # -- one stream synchronisation, as for the fixed-trip CG counter -- and a flagged call is redone eagerly, where
         # UNetModel.guarded() falls back to the bf16-headed arithmetic
         model = getattr(self.den, "inner_model", None) or getattr(getattr(self.den, "denoiser", None), "inner_model", None)
-        if getattr(model, "x3_guard", False) and getattr(model, "dtype", None) == "f16x3" and (model.x3_saturated() & 1):
+        if getattr(model, "x3_guard", False) and getattr(model, "dtype", None) == "f16x3" and (model.x3_saturated() & 5):
             self.x3_redone += 1
             self.eager_calls += 1
             return self.den(x, sigma)

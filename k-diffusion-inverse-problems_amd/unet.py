@@ -91,6 +91,15 @@ class UNetModel:
         self.x3_guard = dtype == "f16x3"
         self.x3_fallbacks = 0          # calls redone bf16-headed
         self.x3_degraded = 0           # ... of which the bf16-headed pass itself lost tail precision on some operand (bit 0 of the flag)
+        # A VJP whose gradient tensors sit under the window (whole launches below 2^-12 of the cotangent's scale: the ImageNet-256
+        # architecture at high sigma) is a property of the network, not of one input.  x3_auto_window = True: after the first such call
+        # every dgrad launch takes its own scale (set_x3_window("launch"), +2 - 3 % per call) instead of a bf16-headed redo call after call.
+        # Off by default: the switch makes a result depend on the handle's history (two runs of one schedule are no longer bitwise equal);
+        # call set_x3_window("launch") up front for such networks, or use dtype "bf16x3".
+        self.x3_auto_window = False
+        self._x3_window = "vjp"
+        self._x3_window_pending = False
+        self.x3_window_switches = 0
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -127,22 +136,34 @@ class UNetModel:
         cov = torch.empty(B, 6, self.image_size, self.image_size, device=x.device) if want_cov else None
         feat = torch.empty(B, self.channel_mult[0] * self.model_channels, self.image_size, self.image_size,
                            device=x.device) if want_feature else None
+        self.before_forward()
         self.guarded(lambda: L.check(self.lib.kdip_unet_forward(self._h, L.stream(), L.ptr(x), L.ptr(t), B, float(in_scale), L.ptr(out),
-                                                                L.ptr(cov), L.ptr(feat))))
+                                                                L.ptr(cov), L.ptr(feat))), "forward")
         return out, cov, feat
+
+    def before_forward(self):
+        """(dtype "f16x3") apply a window-mode switch a flagged VJP asked for: the switch re-plans the workspace and drops the activation
+        stash, so it waits for the next forward (a caller may run several VJPs on one forward)."""
+        if self._x3_window_pending and not torch.cuda.is_current_stream_capturing():
+            self._x3_window_pending = False
+            self.set_x3_window("launch")
+            self.x3_window_switches += 1
 
     def guard_active(self):
         return self.x3_guard and self.dtype == "f16x3" and not torch.cuda.is_current_stream_capturing()
 
-    def guarded(self, call):
+    def guarded(self, call, kind="call"):
         """Run `call` (library launches on the current stream that write their results in place).  dtype "f16x3": poll the fp16-window
         flag afterwards (one stream synchronisation) and, if some operand left the window, run `call` again in the bf16-headed
         arithmetic (kdip_unet_x3_head) -- the result a "bf16x3" handle would have produced."""
         call()
         if not self.guard_active():
             return
-        if self.x3_saturated() & 1:
+        flag = self.x3_saturated()
+        if flag & 5:                      # bit 0: an operand above the fp16 window, bit 2: a launch's whole operand tensor below it
             self.x3_fallbacks += 1
+            if (flag & 4) and kind != "forward" and self.x3_auto_window and self._x3_window == "vjp":
+                self._x3_window_pending = True
             L.check(min(self.lib.kdip_unet_x3_head(self._h, 1), 0))
             try:
                 call()
@@ -156,6 +177,7 @@ class UNetModel:
         if mode not in ("vjp", "launch"):
             raise ValueError("mode must be 'vjp' or 'launch'")
         L.check(self.lib.kdip_unet_x3_window(self._h, 1 if mode == "launch" else 0))
+        self._x3_window = mode
 
     def x3_saturated(self, reset=True):
         """dtype "bf16x3" / "f16x3" only: flags of operands that left the fp16 window of the split-precision convs since the last reset (bit 0:
@@ -183,7 +205,7 @@ class UNetModel:
         cot = cot.contiguous()
         B = cot.shape[0]
         gx = torch.empty(B, self.in_channels, self.image_size, self.image_size, device=cot.device)
-        self.guarded(lambda: L.check(self.lib.kdip_unet_vjp(self._h, L.stream(), L.ptr(cot), B, L.ptr(gx))))   # the library rejects B != batch of the last forward
+        self.guarded(lambda: L.check(self.lib.kdip_unet_vjp(self._h, L.stream(), L.ptr(cot), B, L.ptr(gx))), "vjp")   # the library rejects B != batch of the last forward
         return gx
 
     def forward(self, x, timesteps, y=None, return_feature=False):

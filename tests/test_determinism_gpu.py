@@ -49,7 +49,7 @@ def test_unet_forward_vjp_bitwise_reproducible(dt):
     assert torch.equal(out2, runs[0][0]) and torch.equal(m.vjp(cot), runs[0][1])
 
 
-@pytest.mark.parametrize("dt", ["f32", "bf16x3"])
+@pytest.mark.parametrize("dt", ["f32", "bf16x3", "f16x3"])
 def test_tiny_unet_bitwise_reproducible(dt):
     """The tiny golden-vector architecture (32 base channels: one channel per GroupNorm group, the general path of the ordered
     statistics; attention at 32 x 32), batch 5."""
@@ -72,7 +72,7 @@ def test_tiny_unet_bitwise_reproducible(dt):
 RUNS = [("gaussian_blur", "I", "convert", {}), ("inpainting", "dps", "dps", dict(zeta=1.0)), ("super_resolution", "II", "pgdm", {})]
 
 
-@pytest.mark.parametrize("dt", ["f32", "bf16x3"])
+@pytest.mark.parametrize("dt", ["f32", "bf16x3", "f16x3"])
 @pytest.mark.parametrize("opn,guid,cov,extra", RUNS)
 def test_sampler_run_bitwise_reproducible(dt, opn, guid, cov, extra):
     """A 20-step Heun `--ode` run (39 guided calls, sigma 80 -> 0.01: closed-form and CG branches of the mat-solver, hand-written VJP,
@@ -96,7 +96,7 @@ def test_sampler_run_bitwise_reproducible(dt, opn, guid, cov, extra):
     assert nd == 0, (dt, opn, nd, float((a - b).abs().max()))
 
 
-@pytest.mark.parametrize("dt", ["f32", "bf16x3"])
+@pytest.mark.parametrize("dt", ["f32", "bf16x3", "f16x3"])
 @pytest.mark.parametrize("cid", ["cfg3_imagenet_motion_typeI_analytic", "cfg4_gauss_v2_dwt_autoI"])
 def test_other_baseline_configs_bitwise_reproducible(dt, cid):
     """BASELINE configs[3] (ImageNet-256 architecture: 16 attention blocks on the fp32 GEMM + softmax path, analytic covariance) and

@@ -40,7 +40,7 @@ def test_harness_runs(tmp_path, op, extra):
     assert len(pngs) == 3, pngs          # 1 measurement + 2 samples
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16x3"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16x3", "f16x3"])
 @pytest.mark.parametrize("task,sampler,extra", [
     ("gaussian_deblur_64", "heun", ["--guidance", "I", "--xstart-cov-type", "convert"]),
     ("gaussian_deblur_64", "euler", ["--guidance", "I", "--xstart-cov-type", "convert", "--euler"]),

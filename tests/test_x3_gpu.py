@@ -228,8 +228,36 @@ def test_f16x3_out_of_window_call_is_redone_bf16_headed():
     ob = mb.forward_raw(x * 1e7, t)[0].clone()
     oh = mh.forward_raw(x * 1e7, t)[0].clone()
     assert mh.x3_fallbacks == 1 and torch.isfinite(oh).all() and torch.equal(oh, ob)
+    # the LOW side of the window: with activations of 1e7 the GroupNorm backward scales every internal gradient by ~1e-7 of the cotangent
+    # the VJP's window follows -- whole gradient tensors under the fp16 head's normal range (2^-14), where it would lose them.  Each launch
+    # reports its largest staged operand, the end-of-pass check raises bit 2, and the VJP is redone bf16-headed as well.
+    cot = torch.randn(2, 6, 64, 64, generator=g).cuda()
+    vb = mb.vjp(cot).clone()
+    vh = mh.vjp(cot).clone()
+    assert mh.x3_fallbacks == 2 and torch.equal(vh, vb), float((vh - vb).abs().max() / vb.abs().max())
     o2 = mh.forward_raw(x, t)[0]
-    assert mh.x3_fallbacks == 1 and torch.equal(o1, o2)
+    mh.vjp(cot)
+    assert mh.x3_fallbacks == 2 and torch.equal(o1, o2)
     mh.x3_guard = False                               # the caller polls itself (what graphs.py does around a replay)
     mh.forward_raw(x * 1e7, t)
-    assert mh.x3_saturated() & 1 and mh.x3_fallbacks == 1
+    assert mh.x3_saturated() & 1 and mh.x3_fallbacks == 2
+    mh.vjp(cot)
+    assert mh.x3_saturated() & 4
+    # policy: gradient tensors under the window are a property of the network -- with x3_auto_window (opt-in) the first flagged VJP makes every
+    # later dgrad launch take its own scale (set_x3_window("launch") at the next forward) instead of a bf16-headed redo per call
+    mh.x3_guard, mh.x3_auto_window = True, True
+    mh.forward_raw(x * 1e7, t)
+    mh.vjp(cot)
+    assert mh._x3_window_pending and mh._x3_window == "vjp"
+    n = mh.x3_fallbacks
+    mh.forward_raw(x * 1e7, t)                        # (its activations still leave the window: redone bf16-headed; the switch happened before it)
+    assert mh._x3_window == "launch" and mh.x3_window_switches == 1
+    n = mh.x3_fallbacks
+    vl = mh.vjp(cot)
+    assert mh.x3_fallbacks == n and torch.isfinite(vl).all()      # per-launch scales: the fp16-headed VJP is inside its window now
+    mf = ku.UNetModel(dtype="f32", **kw).load_state_dict(sd)
+    mf.forward_raw(x * 1e7, t)
+    vf = mf.vjp(cot)
+    el, eb = float((vl - vf).abs().max() / vf.abs().max()), float((vb - vf).abs().max() / vf.abs().max())
+    print(f"\nactivations of 1e7: VJP rel-max vs f32: f16x3 with per-launch windows {el:.2e}, bf16x3 (tails lost, head only) {eb:.2e}")
+    assert el < max(eb, 1e-4)                         # at least what the bf16-headed arithmetic delivers out there
