@@ -110,9 +110,9 @@ def main():
     p.add_argument("--v2", action="store_true", help="the DWT-Var / DCT-Var path of sample_condition_openai_v2.py")
     p.add_argument("--spatial-var", dest="spatial_var", action="store_true", help="(v2) pixel-space instead of transform-space variance")
     # MI355X build only
-    p.add_argument("--dtype", choices=["bf16", "f32", "bf16x3", "f16x3"], default="bf16x3",
-                   help="UNet arithmetic: bf16x3 (default) = fp32 storage + split-precision convs, the reference's fp32 results to 1e-3 dB at 2.2x the speed of "
-                        "f32 (exact-f32 MFMA); bf16 = throughput mode, 2.4x faster again, |dPSNR| ~1e-2 dB")
+    p.add_argument("--dtype", choices=["bf16", "f32", "bf16x3", "f16x3"], default="f16x3",
+                   help="UNet arithmetic: f16x3 (default) / bf16x3 = fp32 storage + split-precision convs (fp16- / bf16-headed; f16x3 polls a two-sided fp16-window watch per call and "
+                        "redoes a flagged call in bf16x3), the reference's fp32 results to 1e-3 dB at 2.3x / 2.2x the speed of f32 (exact-f32 MFMA); bf16 = throughput mode, 2.3x faster again, |dPSNR| ~1e-2 dB")
     p.add_argument("--synthetic-weights", action="store_true", help="seeded random-init weights when the checkpoint is absent")
     p.add_argument("--synthetic-data", type=int, default=0, metavar="N", help="N seeded smooth images when the dataset folder is absent")
     p.add_argument("--seed", type=int, default=0)

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize("op,extra", [
     ("gaussian_deblur", ["--guidance", "I", "--xstart-cov-type", "convert", "--ode"]),
     ("gaussian_deblur", ["--guidance", "I", "--xstart-cov-type", "convert", "--streams", "2"]),      # two part-batches on two HIP streams / threads
-    ("gaussian_deblur", ["--guidance", "I", "--xstart-cov-type", "convert", "--dtype", "bf16"]),     # the throughput mode (the harness defaults to bf16x3)
+    ("gaussian_deblur", ["--guidance", "I", "--xstart-cov-type", "convert", "--dtype", "bf16"]),     # the throughput mode (the harness defaults to f16x3)
     ("gaussian_deblur", ["--config", "configs/models.json#ffhq_dwt", "--guidance", "autoI", "--ode"]),     # v2 script: DWT-Var, CG in the DWT basis
     ("inpainting", ["--config", "configs/models.json#ffhq_dct", "--guidance", "II", "--spatial-var"]),
     ("inpainting", ["--guidance", "dps", "--xstart-cov-type", "dps", "--zeta", "1.0", "--euler", "--ode"]),

@@ -12,7 +12,7 @@ stats bf16x3
 stats bf16x3_1stream_b8 --batch 8 --streams 1
 stats bf16 --dtype bf16
 cd $R
-PMC_TAG=r06 PMC_DTYPE=bf16x3 bash tools/pmc_innetwork.sh > $O/pmc_innetwork_bf16x3.log 2>&1
+PMC_TAG=r06 PMC_DTYPE=${X3DT:-bf16x3} bash tools/pmc_innetwork.sh > $O/pmc_innetwork_${X3DT:-bf16x3}.log 2>&1
 for d in a b c d e; do f=$(find gpurun_out/pmcnet/$d -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp $f $O/pmc_innetwork_bf16x3_${d}_counter_collection.csv; done
 cp gpurun_out/pmcnet/dump_a.csv $O/pmc_innetwork_bf16x3_launch_records.csv 2>/dev/null
 cp gpurun_out/pmcnet/r06_pmc_innetwork_bf16x3.json $O/ 2>/dev/null
