@@ -306,8 +306,11 @@ static_assert(KDIP_SPLITK_MAX >= 1 && KDIP_SPLITK_MAX <= 64, "KDIP_SPLITK_MAX (k
 #define KDIP_X3_SUBS1_SMALL 1
 #endif
 #ifndef KDIP_X3_LAYOUT14
-#define KDIP_X3_LAYOUT14 0   // 1: the split-precision 128 x 128 3x3 tile as 1 x 4 waves of 128 px x 32 co (no weight fragment is fetched or re-encoded twice; every wave reads all A fragments)
-#endif
+#define KDIP_X3_LAYOUT14 0   // 1: the bf16-headed split-precision 128 x 128 3x3 tile as 1 x 4 waves of 128 px x 32 co (no weight fragment is fetched or re-encoded twice; every wave reads
+#endif                       //    all A fragments).  Three A planes: LDS-bound, measured slower (96.4 -> 97.8 / 101.9 ms at two / three blocks per CU)
+#ifndef KDIP_H3_LAYOUT14
+#define KDIP_H3_LAYOUT14 1   // ... for the fp16-headed split (two A planes: 96 instead of 144 KB of fragment reads per k-step and CU) the same layout wins: no weight fragment crosses the
+#endif                       //    vector L1 twice, 168 VGPRs without a spill at three blocks per CU: 128 -> 128 @ 256^2 462 -> 452 us, step 90.9 -> 89.7 ms (profiles/r06/ab_layout14_f16x3.log)
 #ifndef KDIP_X3_B_DEPTH
 #define KDIP_X3_B_DEPTH 2    // ... and the weight-fragment stages in flight of their 3x3 instantiations (two 16-byte planes per fragment): 2 measured
                              // +4 - 6 % over 1 on the large maps; the 1x1 instantiations keep 1 (-6 % with 2)
@@ -1594,7 +1597,7 @@ static int launch_T(ConvParams& p, hipStream_t st) {
   const long mt = cdiv((long)p.B * p.H * p.W, 128);
   // (a 256x128 block with 128x64 wave tiles and a 1x4 wave layout were measured and rejected: DESIGN.md section 5,
   // tools/experiments/)
-  if constexpr (KDIP_X3_LAYOUT14 && X3Tag<T>::is && NTAPS == 9) {
+  if constexpr (((KDIP_X3_LAYOUT14 && X3Tag<T>::mode != 2) || (KDIP_H3_LAYOUT14 && X3Tag<T>::mode == 2)) && NTAPS == 9) {
     if (npad >= 128 && mt * cdiv(npad, 128) >= 512) return launch_cfg<T, NTAPS, 1, 4, 4, 1>(p, st);
   }
   if (npad >= 128 && mt * cdiv(npad, 128) >= 512) return launch_cfg<T, NTAPS, 2, 2, 2, 2>(p, st);
