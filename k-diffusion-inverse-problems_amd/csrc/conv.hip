@@ -311,6 +311,16 @@ static_assert(KDIP_SPLITK_MAX >= 1 && KDIP_SPLITK_MAX <= 64, "KDIP_SPLITK_MAX (k
 #ifndef KDIP_H3_LAYOUT14
 #define KDIP_H3_LAYOUT14 1   // ... for the fp16-headed split (two A planes: 96 instead of 144 KB of fragment reads per k-step and CU) the same layout wins: no weight fragment crosses the
 #endif                       //    vector L1 twice, 168 VGPRs without a spill at three blocks per CU: 128 -> 128 @ 256^2 462 -> 452 us, step 90.9 -> 89.7 ms (profiles/r06/ab_layout14_f16x3.log)
+#ifndef KDIP_H3_ROWREUSE
+#define KDIP_H3_ROWREUSE 1   // fp16-headed 1 x 4 tile: 32 x 4-pixel patches, so an m-tile is one output row and the A fragment of halo row r at column tap kx serves the three
+#endif                       //    row taps (output rows r, r - 1, r - 2) from registers: 18 instead of 36 fragment reads per 16-channel k-step (taps walked column-major), 48 instead of
+                             //    64 fragment registers.  Alone +-0 (the LDS pipe was not the limiter: 87.9 / 88.8 vs 88.7 / 88.0 ms per step, shader clock +3 %); with the registers it
+                             //    frees spent on a second weight stage in the GroupNorm-staging instantiation: 86.6 / 86.4 vs 88.7 / 88.0 and 90.7 / 91.0 vs 92.2 / 92.2 ms on a second box
+                             //    (profiles/r06/ab_rowreuse.log, ab_rowreuse2.log).  The same second stage without row reuse spills (24 B): 91.7 / 91.9
+// instantiations whose A fragments are shared by the three row taps
+template <typename T, int NTAPS, int WAVES_M, int MT, int NT, int SUBS> constexpr bool rowreuse_of() {
+  return KDIP_H3_ROWREUSE && X3Tag<T>::mode == 2 && NTAPS == 9 && WAVES_M == 1 && MT == 4 && NT == 1 && SUBS == 1 && KDIP_X3_KC == 16;
+}
 #ifndef KDIP_X3_B_DEPTH
 #define KDIP_X3_B_DEPTH 2    // ... and the weight-fragment stages in flight of their 3x3 instantiations (two 16-byte planes per fragment): 2 measured
                              // +4 - 6 % over 1 on the large maps; the 1x1 instantiations keep 1 (-6 % with 2)
@@ -772,6 +782,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (X3Tag<T>::is) ? (MT * NT ==
   constexpr int HALO = (NTAPS == 9) ? 1 : 0;
   constexpr int MAXPIX = (NTAPS == 1) ? BM : ((BM == 256) ? 400 : 256);
   constexpr int MAXV = (MAXPIX * VPP + NTHREADS - 1) / NTHREADS;   // staged 16-byte vectors per thread
+  // row reuse (launch_cfg2 gives these instantiations TW = 32, TH = 4: m-tile mt = output row mt of the patch)
+  constexpr bool RR = rowreuse_of<T, NTAPS, WAVES_M, MT, NT, SUBS>();
+  static_assert(!RR || KS == 1, "row reuse is written for one k-step per stage");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   constexpr bool PERSIST_K = KDIP_PERSIST && sizeof(T) == 2 && NTAPS == 9 && SUBS == 1;   // instantiations that may run persistently
@@ -1028,7 +1041,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (X3Tag<T>::is) ? (MT * NT ==
   const int nstages = nchunks_all * SUBS * NTAPS;
   auto load_b = [&](uint4 (&dst)[KS][NT][NPB], int stage) {
     stage = stage < nstages ? stage : nstages - 1;
-    const int c32 = stage / NTAPS, tp = stage - c32 * NTAPS;
+    const int c32 = stage / NTAPS;
+    int tp = stage - c32 * NTAPS;
+    if constexpr (RR) tp = (tp % 3) * 3 + tp / 3;      // stages walk the taps column by column: stage kx * 3 + ky is tap (ky, kx)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -1038,7 +1053,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (X3Tag<T>::is) ? (MT * NT ==
   };
   // the staging-transform instantiation trades the A-fragment prefetch (KDIP_X3_TF_APF 0: 48 registers) for the second weight stage
   constexpr bool APF = KDIP_A_PREFETCH && !(X3 && TFM && !KDIP_X3_TF_APF);
-  constexpr int BD = X3 ? ((NTAPS == 9 && (!TFM || !KDIP_X3_TF_APF || KDIP_X3_TF_BD2)) ? (MT * NT <= 2 ? KDIP_X3_B_DEPTH_SMALL : KDIP_X3_B_DEPTH) : 1) : (MT * NT <= 2 && sizeof(T) == 2 && NTAPS == 9) ? KDIP_B_DEPTH_SMALL : KDIP_B_DEPTH;   // stages ahead
+  // (row reuse holds 48 instead of 64 fragment registers: its GroupNorm-staging instantiation affords the second weight stage as well, -1 % per step)
+  constexpr int BD = X3 ? ((NTAPS == 9 && (!TFM || !KDIP_X3_TF_APF || KDIP_X3_TF_BD2 || (RR && TFM == 1))) ? (MT * NT <= 2 ? KDIP_X3_B_DEPTH_SMALL : KDIP_X3_B_DEPTH) : 1) : (MT * NT <= 2 && sizeof(T) == 2 && NTAPS == 9) ? KDIP_B_DEPTH_SMALL : KDIP_B_DEPTH;   // stages ahead
   uint4 bq[BD + 1][KS][NT][NPB];
 
   // prologue: the first two B stages are requested together with the first patch, ahead of the LDS write + barrier
@@ -1084,6 +1100,51 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (X3Tag<T>::is) ? (MT * NT ==
     // issue them after the first stage's MFMAs instead (3x3), so only the old B loads are waited for.
     if (!KDIP_ABL_NOSTAGE && NTAPS * SUBS == 1) next_load(c);
     const unsigned char* abuf = smem + buf * abuf_bytes;
+    if constexpr (RR) {
+      // Row reuse.  The patch is 6 halo rows of 34 pixels and m-tile mt is output row mt, so tap (ky, kx) multiplies m-tile mt with halo row
+      // mt + ky at column offset kx: the six row fragments of one kx serve all three ky from registers (18 instead of 36 two-plane fragment
+      // reads per k-step: LDS fragment traffic per CU 96 -> 48 KB per tap triple).  A row's registers are re-loaded for kx + 1 as soon as its
+      // last reader (ky = 0 for row 0, ky = 1 for row 1, ky = 2 for rows 2 - 5) has been issued.
+      const unsigned char* a0 = abuf + abase[0];
+      auto ldrow = [&](uint4 (&d)[NPA], int r, int kx) {
+#pragma unroll
+        for (int pl = 0; pl < NPA; ++pl) d[pl] = *(const uint4*)(a0 + r * ROWB + kx * PIXB + pl * (KCH * 2));
+      };
+      uint4 F[6][NPA];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) ldrow(F[r], r, 0);
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const int s9 = kx * 3 + ky;
+          if (!KDIP_ABL_NOB) load_b(bq[BD], c * NTAPS + s9 + BD);
+          const uint4 bh0 = make_uint4(0, 0, 0, 0);
+#define KDIP_RR_PASS(TERM)                                                                                      \
+          _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                      \
+            Mma<T>::template run<TERM>(F[mt + ky], bq[0][0][0], bh0, acc[mt][0]);
+          KDIP_RR_PASS(0) KDIP_RR_PASS(1) KDIP_RR_PASS(2)
+#undef KDIP_RR_PASS
+          if (!KDIP_ABL_NOSTAGE && s9 == 0) next_load(c);
+          if (!KDIP_ABL_NOSTAGE && EW_AT > 0 && s9 == EW_AT && stage_next) stage_write(buf ^ 1);
+#pragma unroll
+          for (int i = 0; i < BD; ++i)
+#pragma unroll
+            for (int pl = 0; pl < NPB; ++pl) bq[i][0][0][pl] = bq[i + 1][0][0][pl];
+          // refill: a row's registers are re-loaded for the next column tap as soon as their last reader has been issued.  (One or two spare
+          // slots that take rows 2, 3 of the next column tap a few stages early measured slower: 12 - 52 B of scratch at the 168-register budget,
+          // 91.7 / 95.0 vs 90.8 ms per step, profiles/r06/ab_rowreuse2.log)
+          if (kx < 2) {
+            if (ky == 0) ldrow(F[0], 0, kx + 1);
+            else if (ky == 1) ldrow(F[1], 1, kx + 1);
+            else {
+#pragma unroll
+              for (int r = 2; r < 6; ++r) ldrow(F[r], r, kx + 1);
+            }
+          }
+        }
+      }
+    } else {
     load_a(aq0, abuf, 0, 0);
 #pragma unroll
     for (int sub = 0; sub < SUBS; ++sub) {
@@ -1137,6 +1198,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (X3Tag<T>::is) ? (MT * NT ==
           if (nsub < SUBS) load_a(aq0, abuf, nsub, ntap);
         }
       }
+    }
     }
     if (!KDIP_ABL_NOSTAGE) {
       if (EW_AT == 0 && stage_next) stage_write(buf ^ 1);
@@ -1405,7 +1467,7 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
   // 32-pixel-wide patches: an MFMA m-tile (32 rows) is one patch row, so the 16-lane groups of
   // ds_read_b128 see 16 consecutive pixels (5-slot stride -> conflict free); 16-wide patches put two
   // patch rows in one m-tile and collide on 2 of 16 slots.
-  const int tw_pref = X3Tag<T>::is ? KDIP_X3_TW : KDIP_TW;
+  const int tw_pref = rowreuse_of<T, NTAPS, WAVES_M, MT, NT, SUBS>() ? 32 : (X3Tag<T>::is ? KDIP_X3_TW : KDIP_TW);
   int TW = p.W < tw_pref ? p.W : tw_pref;
   int TH = p.H < BM / TW ? p.H : BM / TW;
   int TB = BM / (TH * TW);
@@ -1415,6 +1477,8 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
   if (TB > 1 && (TH != p.H || TW != p.W))
     return set_error(KDIP_ERR_UNSUPPORTED, "conv: bad multi-image tile");
   p.TH = TH; p.TW = TW; p.TB = TB;
+  if (rowreuse_of<T, NTAPS, WAVES_M, MT, NT, SUBS>() && !(TW == 32 && TH == 4 && TB == 1))
+    return set_error(KDIP_ERR_UNSUPPORTED, "conv: the row-reuse tile needs W %% 32 == 0 and H %% 4 == 0 (%dx%d)", p.H, p.W);
   p.lgTW = __builtin_ctz(TW); p.lgTHW = __builtin_ctz(TH * TW);
   {
     const int hw = TW + 2 * HALO, hp = (TH + 2 * HALO) * hw;
@@ -1595,10 +1659,11 @@ static int launch_T(ConvParams& p, hipStream_t st) {
   // Small-spatial layers (8x8 ... 32x32) are weight-streaming / latency bound: more, narrower
   // blocks spread the weight reads over more CUs.
   const long mt = cdiv((long)p.B * p.H * p.W, 128);
-  // (a 256x128 block with 128x64 wave tiles and a 1x4 wave layout were measured and rejected: DESIGN.md section 5,
-  // tools/experiments/)
+  // (a 256x128 block with 128x64 wave tiles was measured and rejected: DESIGN.md section 5, tools/experiments/; the 1 x 4 wave layout loses with the
+  // three A planes of the bf16-headed split and wins with the two of the fp16-headed one)
   if constexpr (((KDIP_X3_LAYOUT14 && X3Tag<T>::mode != 2) || (KDIP_H3_LAYOUT14 && X3Tag<T>::mode == 2)) && NTAPS == 9) {
-    if (npad >= 128 && mt * cdiv(npad, 128) >= 512) return launch_cfg<T, NTAPS, 1, 4, 4, 1>(p, st);
+    // (row reuse: 32 x 4-pixel patches, maps of at least 32 x 4)
+    if (npad >= 128 && mt * cdiv(npad, 128) >= 512 && (!rowreuse_of<T, NTAPS, 1, 4, 1, 1>() || (p.W % 32 == 0 && p.H % 4 == 0))) return launch_cfg<T, NTAPS, 1, 4, 4, 1>(p, st);
   }
   if (npad >= 128 && mt * cdiv(npad, 128) >= 512) return launch_cfg<T, NTAPS, 2, 2, 2, 2>(p, st);
   if (npad >= 64 && mt * cdiv(npad, 64) >= 512) return launch_cfg<T, NTAPS, 2, 2, 2, 1>(p, st);

@@ -43,8 +43,13 @@ def _oracle_admissible(oden, hip_raw, hat, x, sigma):
     1e-4 of the boundary in its own x0_raw (oracle/condition.py: clamp_flip), and at most 4 pixels may differ.  The HIP output must
     equal one of the two answers.  Returns (reference nearest to hat, max-abs error against it, [(pixel, oracle x0_raw)] flipped)."""
     oden.clamp_flip = None
-    ref_own = oden(x, sigma)
-    own_raw = oden.last_x0_raw.clone()
+    memo = getattr(oden, "_own_memo", None)      # a test that checks several arithmetic modes against the same oracle call pays for it once
+    if memo is not None and torch.equal(memo[0], x) and torch.equal(memo[1], sigma):
+        ref_own, own_raw, oden.last_borderline = memo[2], memo[3], memo[4]
+    else:
+        ref_own = oden(x, sigma)
+        own_raw = oden.last_x0_raw.clone()
+        oden._own_memo = (x.clone(), sigma.clone(), ref_own, own_raw, list(oden.last_borderline))
     err_own = float((hat - ref_own).abs().max())
     differ = (hip_raw.abs() <= 1) != (own_raw.abs() <= 1)
     idx = [tuple(i) for i in differ.nonzero().tolist()]

@@ -208,6 +208,35 @@ def test_f16x3_conv_error_ladder():
         assert e < 1.2e-6, (scale, e)
 
 
+@pytest.mark.parametrize("case", [(1, 128, 128, 256, 256, 0), (2, 64, 256, 128, 128, 0), (4, 128, 128, 64, 256, 1), (2, 96, 128, 128, 256, 1)])
+def test_f16x3_row_reuse_tile(case):
+    """The chip-filling fp16-headed 3x3 launches (>= 512 tiles of 128 px x 128 co) run the 1 x 4-wave tile on 32 x 4-pixel patches with the A
+    fragments of a halo row shared by the three row taps (KDIP_H3_ROWREUSE, csrc/conv.hip): forward (bias) and input-gradient, square and
+    wide maps, a ragged channel count -- against an fp64 conv, at the error of the other fp16-headed tiles, and finite / exact on the borders
+    (an all-ones input with all-ones weights counts the taps inside the image)."""
+    import kdip_amd._lib as L
+    L.require_gpu()
+    B, Cin, Cout, H, W, dgrad = case
+    g = torch.Generator().manual_seed(17)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    if dgrad:
+        go = torch.randn(B, Cout, H, W, generator=g) * 0.03
+        ref = F.conv_transpose2d(go.double(), w.double(), None, padding=1)
+        y = _conv(L, 3, go, w, None, 9, transpose_flip=1)
+    else:
+        x = torch.randn(B, Cin, H, W, generator=g)
+        b = torch.randn(Cout, generator=g)
+        ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+        y = _conv(L, 3, x, w, b, 9)
+    e = float((y.double() - ref).abs().max() / ref.abs().max())
+    print(f"\nf16x3 row-reuse tile {case}: max|err|/max|ref| {e:.2e}")
+    assert e < 1.2e-6, (case, e)
+    if not dgrad:
+        ones = _conv(L, 3, torch.ones(1, Cin, H, W), torch.ones(Cout, Cin, 3, 3) / 64.0, None, 9)
+        cnt = F.conv2d(torch.ones(1, 1, H, W), torch.ones(1, 1, 3, 3), padding=1) * (Cin / 64.0)
+        assert torch.equal(ones, cnt.expand(1, Cout, H, W)), "tap count on the borders"
+
+
 def test_f16x3_out_of_window_call_is_redone_bf16_headed():
     """dtype "f16x3" is exact-grade only inside the fp16 window of its head planes.  An operand beyond +-65504 (after the power-of-two scaling)
     raises bit 0 of kdip_unet_x3_saturated; UNetModel.guarded() polls it after every forward / VJP / fused guided call and redoes the
