@@ -532,7 +532,7 @@ def main():
         fusion = {"conv3": "plain", "conv3_gnf": "GroupNorm+SiLU fused into the input staging", "conv3_gnb": "GroupNorm backward fused into the input staging"}
         tagparts = key[1].split("_")
         base = "_".join(tagparts[:2]) if len(tagparts) > 1 and tagparts[1] in ("gnf", "gnb") else tagparts[0]
-        desc = fusion.get(base, "first-generation kernel (conv.hip)" + (": split precision, 1 v_mfma_f32_32x32x16_bf16 + 2 v_mfma_f32_32x32x16_f16 per product" if args.dtype == "bf16x3" else (": fp16-headed split precision, 3 v_mfma_f32_32x32x16_f16 per product (every call polled, redone bf16-headed outside the fp16 window)" if args.dtype == "f16x3" else ""))) + ("; GroupNorm forward sums of the output in the epilogue" if "s1" in tagparts else "") + \
+        desc = fusion.get(base, "first-generation kernel (conv.hip)" + (": split precision, 1 v_mfma_f32_32x32x16_bf16 + 2 v_mfma_f32_32x32x16_f16 per product" if args.dtype == "bf16x3" else (": fp16-headed split precision, 3 v_mfma_f32_32x32x16_f16 per product, 1 x 4 waves with a row-reuse K loop on the chip-filling launches (every call polled, redone bf16-headed outside the fp16 window)" if args.dtype == "f16x3" else ""))) + ("; GroupNorm forward sums of the output in the epilogue" if "s1" in tagparts else "") + \
             ("; GroupNorm backward sums of the output in the epilogue" if "s2" in tagparts else "") + ("; residual add" if "res" in tagparts else "")
         names = [lib.kdip_profile_class_name(j).decode() for j in range(n)]
         k = max((j for j in range(n) if names[j].startswith("conv")), key=lambda j: ms[j])

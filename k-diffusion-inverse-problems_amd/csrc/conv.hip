@@ -317,9 +317,16 @@ static_assert(KDIP_SPLITK_MAX >= 1 && KDIP_SPLITK_MAX <= 64, "KDIP_SPLITK_MAX (k
                              //    64 fragment registers.  Alone +-0 (the LDS pipe was not the limiter: 87.9 / 88.8 vs 88.7 / 88.0 ms per step, shader clock +3 %); with the registers it
                              //    frees spent on a second weight stage in the GroupNorm-staging instantiation: 86.6 / 86.4 vs 88.7 / 88.0 and 90.7 / 91.0 vs 92.2 / 92.2 ms on a second box
                              //    (profiles/r06/ab_rowreuse.log, ab_rowreuse2.log).  The same second stage without row reuse spills (24 B): 91.7 / 91.9
+#ifndef KDIP_STATS_FINISH_SPLIT
+#define KDIP_STATS_FINISH_SPLIT 1   // deterministic fused statistics: the finish pass of a big map runs as 8 (2) group ranges per image instead of one block per image
+#endif
+#ifndef KDIP_X3_ROWREUSE
+#define KDIP_X3_ROWREUSE 0   // ... the same loop for the bf16-headed split (needs KDIP_X3_LAYOUT14 1; three A planes: 72 fragment registers)
+#endif
 // instantiations whose A fragments are shared by the three row taps
 template <typename T, int NTAPS, int WAVES_M, int MT, int NT, int SUBS> constexpr bool rowreuse_of() {
-  return KDIP_H3_ROWREUSE && X3Tag<T>::mode == 2 && NTAPS == 9 && WAVES_M == 1 && MT == 4 && NT == 1 && SUBS == 1 && KDIP_X3_KC == 16;
+  return ((KDIP_H3_ROWREUSE && X3Tag<T>::mode == 2) || (KDIP_X3_ROWREUSE && KDIP_X3_LAYOUT14 && X3Tag<T>::mode == 1)) && NTAPS == 9 && WAVES_M == 1 && MT == 4 && NT == 1 &&
+         SUBS == 1 && KDIP_X3_KC == 16;
 }
 #ifndef KDIP_X3_B_DEPTH
 #define KDIP_X3_B_DEPTH 2    // ... and the weight-fragment stages in flight of their 3x3 instantiations (two 16-byte planes per fragment): 2 measured
@@ -368,21 +375,25 @@ __device__ __forceinline__ void conv_stats_handover(const ConvParams& p, float s
   }
 }
 
-// Deterministic modes, second stage (one block of 256 threads per image): the image's slots form tpi rows of NV = Cout_pad / 4 float2
-// (one row per tile); thread (sub = tid / NVB, v = tid % NVB) adds, for each of its vectors, tiles sub, sub + S, sub + 2 S, ... in that
-// order (fp64; coalesced rows, 8 loads in flight), the S partial sums of a vector are then added in order and the vectors of a group
-// in order: one fixed summation tree.  WRITES sums[b][32][2].
+// Deterministic modes, second stage: block (b, gy) owns image b and the 32 / gridDim.y GroupNorm groups [g0, g1), i.e. the vectors [v0, v1) of every tile
+// row of the image's slots (tpi rows of NV = Cout_pad / 4 float2).  Thread (sub = tid / NVB, v = tid % NVB) adds, for each of its vectors, tiles sub,
+// sub + S, sub + 2 S, ... in that order (fp64; 8 loads in flight), the S partial sums of a vector are then added in order and the vectors of a group in
+// order: one fixed summation tree per launch shape.  (One block per image walked 128 KB of slots in 8 dependent round trips on the 256^2 maps: 16 us in
+// the dependency chain between two convs; 8 group ranges per image: one round trip.)  WRITES sums[b][32][2].
 __global__ __launch_bounds__(256) void conv_stats_finish_kernel(const float2* __restrict__ slab, int tpi, int NV, int cpg, double* __restrict__ sums) {
   __shared__ double dsh[512];
-  extern __shared__ __attribute__((aligned(16))) double gsh[];      // [NV][2]
+  extern __shared__ __attribute__((aligned(16))) double gsh[];      // [v1 - v0][2]
   const int tid = threadIdx.x, b = blockIdx.x;
-  const float2* rows = slab + (long)b * tpi * NV;
-  const int NVB = NV < 256 ? NV : 256;              // vectors handled per pass
+  const int gpb = 32 / gridDim.y, g0 = blockIdx.y * gpb;            // groups of this block
+  const int v0 = g0 * cpg / 4, v1 = (g0 + gpb) * cpg / 4;           // cpg % 4 == 0 (launch precondition of the fused statistics)
+  const int nv = v1 - v0;
+  const float2* rows = slab + (long)b * tpi * NV + v0;
+  const int NVB = nv < 256 ? nv : 256;              // vectors handled per pass
   const int S = 256 / NVB;                          // tile sub-sequences
-  for (int vb = 0; vb < NV; vb += NVB) {
+  for (int vb = 0; vb < nv; vb += NVB) {
     const int sub = tid / NVB, v = vb + tid % NVB;
     double da = 0.0, dq = 0.0;
-    if (sub < S && v < NV) {
+    if (sub < S && v < nv) {
       int t = sub;
       for (; t + 7 * S < tpi; t += 8 * S) {
         float2 w[8];
@@ -396,19 +407,19 @@ __global__ __launch_bounds__(256) void conv_stats_finish_kernel(const float2* __
     __syncthreads();
     dsh[tid * 2] = da; dsh[tid * 2 + 1] = dq;
     __syncthreads();
-    if (tid < NVB && vb + tid < NV) {
+    if (tid < NVB && vb + tid < nv) {
       double ra = 0.0, rq = 0.0;
       for (int s2 = 0; s2 < S; ++s2) { ra += dsh[(s2 * NVB + tid) * 2]; rq += dsh[(s2 * NVB + tid) * 2 + 1]; }
       gsh[(vb + tid) * 2] = ra; gsh[(vb + tid) * 2 + 1] = rq;
     }
   }
   __syncthreads();
-  if (tid < 64) {
-    const int g = tid >> 1, k = tid & 1;
-    const int v0 = g * cpg / 4, v1 = (g + 1) * cpg / 4;          // cpg % 4 == 0 (launch precondition of the fused statistics)
+  if (tid < gpb * 2) {
+    const int gl = tid >> 1, k = tid & 1;
+    const int w0 = gl * cpg / 4, w1 = (gl + 1) * cpg / 4;
     double r = 0.0;
-    for (int v = v0; v < v1; ++v) r += gsh[v * 2 + k];
-    sums[((long)b * 32 + g) * 2 + k] = r;
+    for (int v = w0; v < w1; ++v) r += gsh[v * 2 + k];
+    sums[((long)b * 32 + g0 + gl) * 2 + k] = r;
   }
 }
 
@@ -1119,7 +1130,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (X3Tag<T>::is) ? (MT * NT ==
         for (int ky = 0; ky < 3; ++ky) {
           const int s9 = kx * 3 + ky;
           if (!KDIP_ABL_NOB) load_b(bq[BD], c * NTAPS + s9 + BD);
-          const uint4 bh0 = make_uint4(0, 0, 0, 0);
+          const uint4 bh0 = XMODE == 1 ? bf16x8_to_f16x8(bq[0][0][0][0]) : make_uint4(0, 0, 0, 0);      // (bf16-headed split: the weight head re-encoded as f16)
 #define KDIP_RR_PASS(TERM)                                                                                      \
           _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                      \
             Mma<T>::template run<TERM>(F[mt + ky], bq[0][0][0], bh0, acc[mt][0]);
@@ -1612,7 +1623,9 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
   }
   if ((p.st_mode == 1 || p.st_mode == 2) && p.det_slab) {
     const int NV = nblkN * (BN / 4);
-    hipLaunchKernelGGL(conv_stats_finish_kernel, dim3(p.B), dim3(256), (size_t)NV * 2 * sizeof(double), st, (const float2*)p.det_slab, p.tilesX * p.tilesY, NV,
+    const int tpi = p.tilesX * p.tilesY;
+    const int gy = !KDIP_STATS_FINISH_SPLIT ? 1 : (tpi >= 64 ? 8 : (tpi >= 16 ? 2 : 1));      // group ranges per image (a function of the launch shape only: fixed summation tree)
+    hipLaunchKernelGGL(conv_stats_finish_kernel, dim3(p.B, gy), dim3(256), (size_t)NV * 2 * sizeof(double), st, (const float2*)p.det_slab, tpi, NV,
                        p.Cout >> 5, p.st_sums);
   }
   prof_end(st);
