@@ -205,7 +205,10 @@ constexpr int KC = 32;            // input channels per B-pipeline stage (one ta
                                   // steps, interleaved): KC 16 alone +-0; KC 16 + 3 blocks per CU 101.6 -> 97.8 ms per step, 128 -> 128 @ 256^2 509 -> 488 us.  The narrower
                                   // tiles (128x64 / 128x32: small maps) keep 32-channel stages (16: 6.7 -> 7.0 ms per step for the 128x64 class).
 // channels per sub-chunk of an instantiation (TILE = MT * NT accumulator tiles per wave)
-template <typename T, int NTAPS, int TILE> constexpr int kc_of() { return (X3Tag<T>::is && NTAPS == 9 && TILE == 4) ? KDIP_X3_KC : KC; }
+#ifndef KDIP_X3_KC_SMALL
+#define KDIP_X3_KC_SMALL 16       // ... of the 128 x 64 split-precision 3x3 tile (small maps): 16-channel stages bring it to 115 - 116 VGPRs and 28 KB of LDS (32: 239 / 55 KB), see KDIP_X3_OCC_SMALL
+#endif
+template <typename T, int NTAPS, int TILE> constexpr int kc_of() { return (X3Tag<T>::is && NTAPS == 9 && TILE == 4) ? KDIP_X3_KC : ((X3Tag<T>::is && NTAPS == 9 && TILE == 2) ? KDIP_X3_KC_SMALL : KC); }
 #ifndef KDIP_CONV1_NT_LOAD
 #define KDIP_CONV1_NT_LOAD 0     // non-temporal input staging loads of the 1x1 convs: big-map class -3 %, small-map classes +2-4 %, step unchanged
 #endif
@@ -274,6 +277,15 @@ static_assert(KDIP_SPLITK_MAX >= 1 && KDIP_SPLITK_MAX <= 64, "KDIP_SPLITK_MAX (k
 #endif
 #ifndef KDIP_X3_OCC
 #define KDIP_X3_OCC 3        // split-precision 128x128 tiles: resident blocks per CU the register budget is set for (3 needs KDIP_X3_KC 16: LDS)
+#endif
+#ifndef KDIP_X3_OCC1
+#define KDIP_X3_OCC1 KDIP_X3_OCC   // ... of the 128 x 128 split-precision 1x1 tile (HBM-bound skip / qkv / proj convs)
+#endif
+#ifndef KDIP_X3_OCC_SMALL
+#define KDIP_X3_OCC_SMALL 3  // ... of the 128 x 64 split-precision 3x3 tile (small maps).  These launches run beside the OTHER part-batch stream's chip-filling 128 x 128 tiles,
+                             //    whose three blocks hold 504 of a SIMD's 512 registers: a 239-register block displaced TWO of them from its CU for its whole (latency-bound) life.
+                             //    Capped at 168 (3) it displaces one: step 89.9 / 89.8 -> 88.7 / 88.6 ms although the class itself measures 9.1 -> 9.9 ms alone; with 16-channel
+                             //    stages (KDIP_X3_KC_SMALL) no spill and 88.0 / 87.9 ms (profiles/r06/ab_occ_small.log, ab_occ_small2.log)
 #endif
 #ifndef KDIP_EPI32_FOLD2
 #define KDIP_EPI32_FOLD2 0   // fp32-storage epilogue, GroupNorm-backward sums: 1 = taken in the store sweep from prefetched GroupNorm-input rows instead of the second
@@ -773,7 +785,7 @@ __device__ __forceinline__ void epilogue_f32_fast(const ConvParams& p, f32x16 (&
 // transform's registers do not fit next to the two-deep weight pipeline of the plain one)
 // TFM 2: GroupNorm-backward staging of a dgrad conv (two tensors staged: dz and the GroupNorm input; ConvParams::tf_mode 2)
 template <typename T, int NTAPS, int WAVES_M, int WAVES_N, int MT, int NT, int SUBS, int TFM = 0>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (X3Tag<T>::is) ? (MT * NT == 4 ? KDIP_X3_OCC : 2) : (sizeof(T) == 2 && NTAPS == 9) ? (MT * NT == 4 ? KDIP_OCC : (MT * NT == 8 ? 2 : 1)) : ((sizeof(T) == 2 && NTAPS == 1 && MT * NT == 4 && SUBS == 2) ? 3 : 1)) void conv_igemm_kernel(ConvParams p) {
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (X3Tag<T>::is) ? (MT * NT == 4 ? (NTAPS == 1 ? KDIP_X3_OCC1 : KDIP_X3_OCC) : (NTAPS == 9 && MT * NT == 2 ? KDIP_X3_OCC_SMALL : 2)) : (sizeof(T) == 2 && NTAPS == 9) ? (MT * NT == 4 ? KDIP_OCC : (MT * NT == 8 ? 2 : 1)) : ((sizeof(T) == 2 && NTAPS == 1 && MT * NT == 4 && SUBS == 2) ? 3 : 1)) void conv_igemm_kernel(ConvParams p) {
   constexpr bool X3 = X3Tag<T>::is;                        // fp32 storage, operands split into 16-bit hi / lo planes on the way into LDS
   constexpr int XMODE = X3Tag<T>::mode;                    // 1: bf16 head + fp16 tails, 2: fp16 head + fp16 tail
   constexpr int NPA = Mma<T>::NPA, NPB = Mma<T>::NPB, NTERM = Mma<T>::NTERM;
