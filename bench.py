@@ -271,7 +271,10 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="images per GPU (default: the workload's per-GPU batch, 16; cfg0: 1)")
     ap.add_argument("--no-large-batch", action="store_true", help="skip the extra throughput leg at batch 128 (N = 1 only)")
     ap.add_argument("--streams", type=int, default=2, help="part-batches per GPU, each on its own HIP stream + host thread")
-    ap.add_argument("--stagger-ms", type=float, default=0.0, help="start part-batch k of a GPU k x this many milliseconds after part 0 (phase offset between the streams; inside the timed region)")
+    ap.add_argument("--stagger-ms", type=float, default=-1.0,
+                    help="start part-batch k of a GPU k x this many milliseconds after part 0 (phase offset between the streams; INSIDE the timed region).  -1 (default) = a quarter of a "
+                         "guided call's wall time (forward-only guidance: half), estimated from the last warm-up step: the UNet runs chip-filling convs at both ends of a pass and latency-bound "
+                         "small-map launches in the middle, and two streams started together stay in the same phase; 0 = start together")
     ap.add_argument("--stream-prio", action="store_true", help="give every second part-batch stream the higher HIP stream priority (scheduling experiment)")
     ap.add_argument("--cu-split", action="store_true", help="give each part-batch stream its own share of the compute units (CU-masked HIP streams)")
     ap.add_argument("--dtype", choices=("bf16", "f32", "bf16x3", "f16x3"), default="f16x3",
@@ -363,10 +366,12 @@ def main():
             x = ks.heun_step(pt["den"], x, sig, i) if heun else ks.sample_euler(pt["den"], x, sig[i:i + 2], disable=True)
         return x
 
+    stagger = {"ms": max(args.stagger_ms, 0.0)}            # (auto: set by timed_run from its last warm-up step)
+
     def run_all(parts, steps, chain):
         from kdip_amd.evaluation import run_on_streams
         outs = run_on_streams([lambda pt=pt: run_part(pt, steps, chain) for pt in parts], [pt["stream"] for pt in parts], dev,
-                              delays=[k * args.stagger_ms * 1e-3 for k in range(len(parts))] if args.stagger_ms > 0 else None)
+                              delays=[k * stagger["ms"] * 1e-3 for k in range(len(parts))] if stagger["ms"] > 0 else None)
         torch.cuda.synchronize()
         return torch.cat(outs)
 
@@ -374,7 +379,15 @@ def main():
         """warm-up (one closed-form and one CG step per pair: allocates the workspaces), then barrier-bracketed timing incl. the
         one collective of the path (RCCL all_gather); returns max-over-ranks seconds."""
         if warmup > 0:
-            run_all(parts, [NS // 10 if w % 2 == 0 else NS * 95 // 100 for w in range(warmup)], False)
+            wsteps = [NS // 10 if w % 2 == 0 else NS * 95 // 100 for w in range(warmup)]
+            if len(wsteps) > 1:
+                run_all(parts, wsteps[:-1], False)
+            torch.cuda.synchronize()
+            tw = time.perf_counter()
+            run_all(parts, wsteps[-1:], False)
+            if args.stagger_ms < 0 and len(parts) > 1 and len(wsteps) > 1:      # phase offset = a quarter (forward-only guidance: half) of one guided call with all streams running
+                call_ms = (time.perf_counter() - tw) * 1e3 / (2 if heun else 1)
+                stagger["ms"] = round(call_ms / (2 if WL["guidance"] == "II" else 4), 2)
         torch.cuda.synchronize()
         env.barrier()
         torch.cuda.synchronize()
@@ -411,7 +424,7 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": f"synthetic (seeded smooth images, random-init {WL['arch']}-architecture weights)",
         "config": {"workload": WL["label"] + ", batch " + str(B) + " per GPU", "reference": WL["ref"],
-                   "global_batch": env.world_size * B, "per_gpu_batch": B, "streams_per_gpu": S_, "images_per_launch": parts[0]["B"],
+                   "global_batch": env.world_size * B, "per_gpu_batch": B, "streams_per_gpu": S_, "stream_phase_offset_ms": stagger["ms"], "images_per_launch": parts[0]["B"],
                    "calls_per_image": calls_per_image,
                    "timed_steps": f"full {NS}-step sampler run" if full_run else (f"two-call Heun steps spread evenly over steps 0..{NS - 2} of the {NS}-step schedule (the single-call final step is never in a subset)" if heun else f"Euler steps spread evenly over the {NS}-step schedule"),
                    "parallelism": f"dp{env.world_size} (independent images, one all_gather at the end)"},

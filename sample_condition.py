@@ -123,6 +123,8 @@ def main():
                    "the reference's CPU path): a run is then comparable value for value with a run of the reference on the same seeds")
     p.add_argument("--streams", type=int, default=1, help="split each sampler batch into this many part-batches, each with its own "
                    "UNet handle / operator context / HIP stream / host thread (overlaps HBM-bound and MFMA-bound phases)")
+    p.add_argument("--stream-offset-ms", type=float, default=10.0, help="with --streams > 1: part-batch k starts k x this many milliseconds after part 0, so that the "
+                   "streams do not run the same phase of the UNet (large maps / small maps) at the same time; about a quarter of one guided call (bench.py measures it)")
     args = p.parse_args()
 
     if args.cpu_rng:
@@ -236,7 +238,8 @@ def main():
                 return sample_part(cond_models[0], x)
             torch.cuda.synchronize()
             chunks = x.chunk(k)
-            outs = ke.run_on_streams([lambda m=cond_models[j], c=chunks[j]: sample_part(m, c.contiguous()) for j in range(len(chunks))], device=device)
+            outs = ke.run_on_streams([lambda m=cond_models[j], c=chunks[j]: sample_part(m, c.contiguous()) for j in range(len(chunks))], device=device,
+                                     delays=[j * args.stream_offset_ms * 1e-3 for j in range(len(chunks))] if args.stream_offset_ms > 0 else None)
             return torch.cat(outs)
 
         hat_x0 = ke.compute_features(env, sample_fn, lambda x: x, args.n, args.batch_size)
