@@ -118,6 +118,13 @@ def build_problem(WL, dtype, dev, Bk, sd, D, seed=0, S=256):
     ARCH = ku.FFHQ_CONFIG if WL["arch"] == "FFHQ" else ku.IMAGENET_CONFIG
     model = ku.UNetModel(dtype=dtype, device=dev, **ARCH)
     model.load_state_dict(sd)
+    # fp16 window of the VJP's gradient operands.  Default: one power-of-two scale per VJP (from max |cotangent|).  The ImageNet-256 architecture's high-sigma
+    # gradients span more than that window holds (12 - 15 dgrad launches per call at 5e-5 ... 2e-4 of the cotangent): in f16x3 every such call would be flagged and
+    # redone bf16-headed (623 ms per step), so this workload lets every dgrad launch scale by a sampled maximum of its own input (deterministic: a function of the
+    # data; 453 vs 475 ms for bf16x3, no call flagged -- profiles/r06/ab_cfg3_window.log).  KDIP_BENCH_X3_WINDOW=vjp|launch overrides.
+    win = os.environ.get("KDIP_BENCH_X3_WINDOW", "launch" if (WL["arch"] == "IMAGENET" and dtype == "f16x3") else "vjp")
+    if dtype in ("f16x3", "bf16x3") and win == "launch":
+        model.set_x3_window("launch")
     # operator + synthetic measurement (sigma_s = 0.05), rank- and part-offset seeds: every image is its own problem
     opkw = dict(OPKW[WL["op"]])
     if WL["op"] == "inpainting":

@@ -123,6 +123,8 @@ def main():
                    "the reference's CPU path): a run is then comparable value for value with a run of the reference on the same seeds")
     p.add_argument("--streams", type=int, default=1, help="split each sampler batch into this many part-batches, each with its own "
                    "UNet handle / operator context / HIP stream / host thread (overlaps HBM-bound and MFMA-bound phases)")
+    p.add_argument("--x3-window", choices=["vjp", "launch"], default="vjp", help="split-precision modes: fp16 window of the VJP's gradient operands -- one scale per VJP (default) or one per "
+                   "dgrad launch (networks whose gradients span more than one window, e.g. the ImageNet-256 architecture at high sigma: avoids f16x3's bf16-headed redo calls)")
     p.add_argument("--stream-offset-ms", type=float, default=10.0, help="with --streams > 1: part-batch k starts k x this many milliseconds after part 0, so that the "
                    "streams do not run the same phase of the UNet (large maps / small maps) at the same time; about a quarter of one guided call (bench.py measures it)")
     args = p.parse_args()
@@ -157,6 +159,8 @@ def main():
         raise FileNotFoundError(f"checkpoint {args.checkpoint} not found (pass --synthetic-weights for random-init weights)")
     for m, _ in models:
         m.load_state_dict(sd)
+        if args.x3_window == "launch" and args.dtype in ("f16x3", "bf16x3"):
+            m.set_x3_window("launch")
     sigma_min, sigma_max = model_config["sigma_min"], model_config["sigma_max"]
 
     if os.path.isdir(dataset_config["location"]):

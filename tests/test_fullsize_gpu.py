@@ -145,6 +145,16 @@ def test_imagenet_unet_fullsize():
     e2h = float((vjph.cpu() - vjp_ref).abs().max() / vjp_ref.abs().max())
     print(f"ImageNet-256 UNet f16x3: fwd rel err {e1h:.2e}, vjp rel err {e2h:.2e} ({mh.x3_fallbacks} passes redone bf16-headed)")
     assert e1h < 5e-4 and e2h < 5e-4
+    # ... with one fp16 window per dgrad launch (what bench.py --workload cfg3 runs in f16x3): the same bound, bitwise repeatable, and no pass flagged
+    mh.set_x3_window("launch")
+    nfb = mh.x3_fallbacks
+    mh.forward_raw(x.cuda(), t.cuda())
+    vl = mh.vjp(cot.cuda())
+    mh.forward_raw(x.cuda(), t.cuda())
+    vl2 = mh.vjp(cot.cuda())
+    e2l = float((vl.cpu() - vjp_ref).abs().max() / vjp_ref.abs().max())
+    print(f"ImageNet-256 UNet f16x3, per-launch windows: vjp rel err {e2l:.2e} ({mh.x3_fallbacks - nfb} passes redone)")
+    assert e2l < 5e-4 and torch.equal(vl, vl2)
 
 
 @pytest.mark.parametrize("sigma_v", [1.5, 0.12])
