@@ -112,11 +112,23 @@ __global__ void silu_f32_kernel(const float* x, long n, float* y) {
     y[i] = z / (1.f + expf(-z));
   }
 }
+// (16-byte loads over the aligned body, scalar tail: the VJP's first launch waits for this pass over the cotangent)
 __global__ void amax_bits_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
   unsigned m = 0;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+  const long nv = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) ? n / 4 : 0;
+  const float4* xv = (const float4*)x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = xv[i];
+    const unsigned b0 = __float_as_uint(v.x) & 0x7fffffffu, b1 = __float_as_uint(v.y) & 0x7fffffffu;
+    const unsigned b2 = __float_as_uint(v.z) & 0x7fffffffu, b3 = __float_as_uint(v.w) & 0x7fffffffu;
+    if (b0 < 0x7f800000u && b0 > m) m = b0;       // finite values only
+    if (b1 < 0x7f800000u && b1 > m) m = b1;
+    if (b2 < 0x7f800000u && b2 > m) m = b2;
+    if (b3 < 0x7f800000u && b3 > m) m = b3;
+  }
+  for (long i = nv * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const unsigned b = __float_as_uint(x[i]) & 0x7fffffffu;
-    if (b < 0x7f800000u && b > m) m = b;          // finite values only
+    if (b < 0x7f800000u && b > m) m = b;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { const unsigned t = __shfl_xor(m, o, 64); m = t > m ? t : m; }
@@ -155,7 +167,7 @@ int amax_bits_sampled(hipStream_t st, const float* x, long n, unsigned* out_zero
 }
 int amax_bits(hipStream_t st, const float* x, long n, unsigned* out) {
   KDIP_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(unsigned), st));
-  long g = (n + 256 * 8 - 1) / (256 * 8); if (g > 1024) g = 1024; if (g < 1) g = 1;
+  long g = (n + 256 * 16 - 1) / (256 * 16); if (g > 1024) g = 1024; if (g < 1) g = 1;
   hipLaunchKernelGGL(amax_bits_kernel, dim3((unsigned)g), dim3(256), 0, st, x, n, out);
   KDIP_LAUNCH_CHECK();
   return KDIP_OK;
