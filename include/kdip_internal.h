@@ -47,6 +47,9 @@ int kdip_debug_conv3_timing(void* dev_buf);
 /* Test / A-B aid: 1 (default) = the large-map bf16 convs compute their GroupNorm staging coefficients from the statistics themselves
  * (no gn_coef / gn_merge_stats / gn_bwd_coef launches between two convs); 0 = separate coefficient kernels.  Results are bit-identical. */
 int kdip_debug_gn_fold(int on);
+/* Test / A-B aid (deterministic modes): 1 (default) = a forward conv with fused GroupNorm statistics leaves their fixed-order finish pass to the consuming
+ * GroupNorm, which runs it inside its coefficient kernel (one launch less between two convs); 0 = finish pass behind the conv.  Results are bit-identical. */
+int kdip_debug_defer_finish(int on);
 /* Diagnostic (KDIP_F16X3 handles): the per-launch peak words of the LAST fp16-headed pass (forward or VJP) -- largest |scaled operand| each conv
  * launch staged, in launch order; *n_host = number of launches (<= max copied).  Synchronises `stream`.  tools/f16x3_check.py prints the
  * distribution: how far real workloads sit from the low side of the fp16 window. */

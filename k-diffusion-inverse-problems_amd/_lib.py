@@ -81,6 +81,7 @@ SIGNATURES = {
     "kdip_test_conv": (C.c_int, [VP, C.c_int, C.c_int, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, C.c_int, C.c_int, VP, C.c_int]),
     "kdip_debug_conv3_timing": (C.c_int, [VP]),
     "kdip_debug_gn_fold": (C.c_int, [C.c_int]),
+    "kdip_debug_defer_finish": (C.c_int, [C.c_int]),
     "kdip_debug_x3_peaks": (C.c_int, [VP, VP, VP, C.c_int, C.POINTER(C.c_int)]),
     "kdip_test_attention": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_int, VP, VP]),
     "kdip_test_conv3": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, C.c_int, C.c_int, C.c_int, VP, VP, C.c_int, C.c_int,

@@ -566,6 +566,7 @@ int kdip_test_conv3(void* stream, const float* x_nchw, const float* x2_nchw, int
 
 int kdip_debug_conv3_timing(void* dev_buf) { return conv3_debug_timing(dev_buf); }
 int kdip_debug_gn_fold(int on) { unet_debug_gn_fold(on); return KDIP_OK; }
+int kdip_debug_defer_finish(int on) { unet_debug_defer_finish(on); return KDIP_OK; }
 
 int kdip_test_groupnorm(void* stream, int dtype, const float* x_nchw, int B, int C, int H, int W, const float* gamma_host,
                         const float* beta_host, const float* film_host, int silu, float* y_nchw, const float* dy_nchw,

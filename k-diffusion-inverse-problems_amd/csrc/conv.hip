@@ -173,6 +173,7 @@ struct ConvParams {
   const void* tf_x2; int tf_mode;      // tf_mode 2: GroupNorm BACKWARD apply while staging: A = a*x - (k0 + k1*x2), tf_coef [B][Cin][4] = (a, b, k0, k1), x2 shares x's layout
   const float* tf_coef; int tf_silu;   // split precision, 3x3: the input is a GroupNorm INPUT; silu?(a*x + b) with (a, b) = tf_coef[B][Cin][2] is applied while
                                   // the patch is staged (conv zero padding applies to the transformed tensor); one image per tile only
+  DetPending* defer;              // deterministic statistics: the finish pass is left to the consumer (ConvStats::defer)
   float* det_slab; size_t det_slab_bytes;   // deterministic modes (det.h): fused statistics go block by block into det_slab [B][tiles per image][n-blocks][BN/4][2] and are
                                   // added in slot order by conv_stats_finish_kernel; split-K partials go to per-split slabs of sk_ws (sk_det)
   int sk_det;
@@ -392,8 +393,13 @@ __device__ __forceinline__ void conv_stats_handover(const ConvParams& p, float s
 // sub + S, sub + 2 S, ... in that order (fp64; 8 loads in flight), the S partial sums of a vector are then added in order and the vectors of a group in
 // order: one fixed summation tree per launch shape.  (One block per image walked 128 KB of slots in 8 dependent round trips on the 256^2 maps: 16 us in
 // the dependency chain between two convs; 8 group ranges per image: one round trip.)  WRITES sums[b][32][2].
-__global__ __launch_bounds__(256) void conv_stats_finish_kernel(const float2* __restrict__ slab, int tpi, int NV, int cpg, double* __restrict__ sums) {
+// COEF: the block also turns its groups' sums into the GroupNorm (+ FiLM) coefficients of their channels -- gn_coef_kernel's arithmetic (norm.hip), so that
+// the consumer's coefficient launch leaves the dependency chain between two convs.
+struct FinishCoef { const float* gamma; const float* beta; const float* film; long film_ld; long HW; int C; float eps; float* coef; float* mr; };
+template <bool COEF>
+__global__ __launch_bounds__(256) void conv_stats_finish_kernel(const float2* __restrict__ slab, int tpi, int NV, int cpg, double* __restrict__ sums, FinishCoef fc) {
   __shared__ double dsh[512];
+  __shared__ double gres[64];
   extern __shared__ __attribute__((aligned(16))) double gsh[];      // [v1 - v0][2]
   const int tid = threadIdx.x, b = blockIdx.x;
   const int gpb = 32 / gridDim.y, g0 = blockIdx.y * gpb;            // groups of this block
@@ -432,7 +438,45 @@ __global__ __launch_bounds__(256) void conv_stats_finish_kernel(const float2* __
     double r = 0.0;
     for (int v = w0; v < w1; ++v) r += gsh[v * 2 + k];
     sums[((long)b * 32 + g0 + gl) * 2 + k] = r;
+    if (COEF) gres[tid] = r;
   }
+  if constexpr (COEF) {
+    __syncthreads();
+    const int cg = fc.C / 32;                                          // channels per group (== cpg)
+    for (int i = tid; i < gpb * cg; i += 256) {
+      const int gl = i / cg, g = g0 + gl, c = g * cg + i % cg;
+      const double n = (double)fc.HW * cg;
+      const double mean = gres[gl * 2] / n;
+      double var = gres[gl * 2 + 1] / n - mean * mean;
+      if (var < 0) var = 0;
+      const float rstd = (float)(1.0 / sqrt(var + (double)fc.eps));
+      const float m = (float)mean;
+      float a = rstd * fc.gamma[c];
+      float bb = fc.beta[c] - m * a;
+      if (fc.film) {
+        const float sc = 1.f + fc.film[(long)b * fc.film_ld + c], sh = fc.film[(long)b * fc.film_ld + fc.C + c];
+        a *= sc;
+        bb = bb * sc + sh;
+      }
+      fc.coef[((long)b * fc.C + c) * 2] = a;
+      fc.coef[((long)b * fc.C + c) * 2 + 1] = bb;
+      if (i % cg == 0) { fc.mr[((long)b * 32 + g) * 2] = m; fc.mr[((long)b * 32 + g) * 2 + 1] = rstd; }
+    }
+  }
+}
+
+int conv_stats_finish(hipStream_t st, const DetPending& pd, int B, double* sums) {
+  hipLaunchKernelGGL(conv_stats_finish_kernel<false>, dim3(B, pd.gy), dim3(256), (size_t)pd.nv * 2 * sizeof(double), st, (const float2*)pd.slab, pd.tpi, pd.nv, pd.cpg, sums, FinishCoef{});
+  KDIP_LAUNCH_CHECK();
+  return KDIP_OK;
+}
+int conv_stats_finish_coef(hipStream_t st, const DetPending& pd, int B, double* sums, const float* gamma, const float* beta, const float* film, long film_ld,
+                           long HW, int C, float eps, float* coef, float* mr) {
+  KDIP_REQUIRE(C == pd.cpg * 32, "conv_stats_finish_coef: the statistics were taken over %d channels, not %d", pd.cpg * 32, C);
+  FinishCoef fc{gamma, beta, film, film_ld ? film_ld : 2L * C, HW, C, eps, coef, mr};
+  hipLaunchKernelGGL(conv_stats_finish_kernel<true>, dim3(B, pd.gy), dim3(256), (size_t)pd.nv * 2 * sizeof(double), st, (const float2*)pd.slab, pd.tpi, pd.nv, pd.cpg, sums, fc);
+  KDIP_LAUNCH_CHECK();
+  return KDIP_OK;
 }
 
 // ---- bf16 fast epilogue ------------------------------------------------------------------
@@ -1637,8 +1681,9 @@ static int launch_cfg2(ConvParams& p, hipStream_t st) {
     const int NV = nblkN * (BN / 4);
     const int tpi = p.tilesX * p.tilesY;
     const int gy = !KDIP_STATS_FINISH_SPLIT ? 1 : (tpi >= 64 ? 8 : (tpi >= 16 ? 2 : 1));      // group ranges per image (a function of the launch shape only: fixed summation tree)
-    hipLaunchKernelGGL(conv_stats_finish_kernel, dim3(p.B, gy), dim3(256), (size_t)NV * 2 * sizeof(double), st, (const float2*)p.det_slab, tpi, NV,
-                       p.Cout >> 5, p.st_sums);
+    if (p.defer) { p.defer->slab = p.det_slab; p.defer->tpi = tpi; p.defer->nv = NV; p.defer->cpg = p.Cout >> 5; p.defer->gy = gy; }      // the consumer of the sums runs the finish pass
+    else hipLaunchKernelGGL(conv_stats_finish_kernel<false>, dim3(p.B, gy), dim3(256), (size_t)NV * 2 * sizeof(double), st, (const float2*)p.det_slab, tpi, NV,
+                            p.Cout >> 5, p.st_sums, FinishCoef{});
   }
   prof_end(st);
   KDIP_LAUNCH_CHECK();
@@ -1721,6 +1766,7 @@ int conv_forward(hipStream_t st, DType dt, int ntaps, const void* x, long ldx, i
   p.x3_lowpeak = (stt && dt == DT_F32H3) ? stt->x3_lowpeak : nullptr;
   const DetWs* det = stt ? stt->det : nullptr;
   p.det_slab = det ? (float*)det->slab : nullptr; p.det_slab_bytes = det ? det->slab_bytes : 0;
+  p.defer = (stt && det) ? stt->defer : nullptr;
   p.sk_det = stt ? stt->sk_det : 0;
   p.tf_coef = stt ? stt->tf_coef : nullptr; p.tf_silu = stt ? stt->tf_silu : 0;
   p.tf_mode = (stt && stt->tf_coef) ? stt->tf_mode : 0; p.tf_x2 = stt ? stt->tf_x2 : nullptr;

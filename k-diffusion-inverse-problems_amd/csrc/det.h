@@ -20,4 +20,11 @@ struct DetWs {
   void* slab = nullptr; size_t slab_bytes = 0;
 };
 
+// A fused-statistics finish pass that the producing conv did NOT launch (ConvStats::defer): the slab (which must then outlive the launch: the
+// handle's persist arena) and the launch geometry the finish needs.  The consumer of the sums runs it -- alone (conv_stats_finish) or together with
+// the GroupNorm coefficient kernel it feeds (conv_stats_finish_coef: one launch instead of two in the dependency chain between two convs).
+struct DetPending {
+  const void* slab = nullptr; int tpi = 0, nv = 0, cpg = 0, gy = 1;
+};
+
 }  // namespace kdip

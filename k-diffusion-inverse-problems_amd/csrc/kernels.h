@@ -37,6 +37,7 @@ struct ConvStats {
   // sk_ws is NOT pre-zeroed and holds one slab [B*H*W][Cout] per K split (sk_ws_floats bounds the number of splits), summed in
   // split order by the finalize pass
   const DetWs* det = nullptr; int sk_det = 0;
+  DetPending* defer = nullptr;     // (with det, modes 1 / 2) the finish pass is left to the consumer of the sums: *defer receives what it needs (det.h)
   // fp32 storage (f32 / split-precision modes), mode 2: the epilogue's backward-statistics sweep also WRITES dz = dy * silu'(a*x + b) over the
   // dy it stored (the lines are still L2-hot), as conv3's st_mode-2 epilogue does for bf16: every consumer of the tensor -- the
   // GroupNorm-backward apply pass, the gnb epilogue below, the TFM-2 staging of the next dgrad conv -- is then transcendental-free
@@ -129,6 +130,11 @@ int gn_stats(hipStream_t st, DType dt, const void* x, long ldx, int B, long HW, 
 // det (fp32 storage only): the sums are reduced in a fixed order through det->slab and WRITTEN (det.h) -- run-to-run bit-reproducible
 // coef[B][C][2] = (a, b) with y = a*x + b  [then SiLU]; a = rstd*gamma*(1+scale), b = (beta - mean*rstd*gamma)*(1+scale)+shift
 // film: [B][2C] fp32 (scale | shift) or null.  Also writes mr[B][32][2] = (mean, rstd) fp32.
+// deferred finish passes of the fused conv statistics (conv.hip): sums [B][32][2] <- slab; the second form also computes the GroupNorm (+ FiLM)
+// coefficients from them (the arithmetic of gn_coef_kernel): coef [B][C][2], mr [B][32][2]
+int conv_stats_finish(hipStream_t st, const DetPending& pd, int B, double* sums);
+int conv_stats_finish_coef(hipStream_t st, const DetPending& pd, int B, double* sums, const float* gamma, const float* beta, const float* film, long film_ld,
+                           long HW, int C, float eps, float* coef, float* mr);
 int gn_coef(hipStream_t st, const double* stats, const float* gamma, const float* beta, const float* film,
             int B, long HW, int C, float eps, float* coef, float* mr, long film_ld = 0);
 int gn_apply(hipStream_t st, DType dt, const void* x, long ldx, const float* coef, int B, long HW, int C, int silu,

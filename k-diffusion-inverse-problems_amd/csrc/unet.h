@@ -5,6 +5,7 @@
 #include <string>
 #include <vector>
 #include "common.h"
+#include "det.h"
 
 namespace kdip {
 
@@ -105,6 +106,7 @@ struct UNet {
   bool det = false;
   float* sk_ws = nullptr; long sk_ws_floats = 0;   // split-K workspace of the small-spatial convs (zeros arena; kept zero by the finalize kernel)
   std::map<std::pair<const void*, int>, double*> fused_stats;   // (tensor, channels) -> GroupNorm sums already accumulated by its producer
+  std::map<const double*, DetPending> pending_stats;            // ... sums whose fixed-order finish pass the producer left to the consumer (det.h: DetPending; slab in `persist`)
   int ws_B = 0;                       // largest batch planned so far
   long ws_generation = 0;             // bumped whenever an arena is re-allocated: captured hipGraphs hold raw arena pointers
   std::map<int, std::array<size_t, 3>> planned;   // batch -> (persist, scratch, zeros) peak bytes of a dry forward + VJP at that batch
@@ -129,6 +131,7 @@ struct UNet {
   size_t esize() const { return dt == DT_BF16 ? 2 : 4; }
 };
 
+void unet_debug_defer_finish(int on);      // A/B switch of the deferred statistics finish (default on; bit-identical results)
 void unet_debug_gn_fold(int on);      // A/B switch of the GroupNorm-coefficient fold (default on)
 
 }  // namespace kdip

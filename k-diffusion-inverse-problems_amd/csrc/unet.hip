@@ -331,6 +331,9 @@ int UNet::finalize() {
 // --------------------------------------------------------------------------- helpers ----
 std::atomic<int> g_gn_fold{[] { const char* e = getenv("KDIP_GN_FOLD"); return e ? (atoi(e) != 0 ? 1 : 0) : 1; }()};      // 1: conv3 computes the GroupNorm staging coefficients itself (no gn_coef / gn_merge_stats / gn_bwd_coef launches)
 void unet_debug_gn_fold(int on) { g_gn_fold.store(on ? 1 : 0); }
+// 1: a forward conv with fused deterministic statistics leaves their finish pass to the GroupNorm that consumes them (finish_pending / gn_forward below)
+std::atomic<int> g_defer_finish{[] { const char* e = getenv("KDIP_DEFER_FINISH"); return e ? (atoi(e) != 0 ? 1 : 0) : 1; }()};
+void unet_debug_defer_finish(int on) { g_defer_finish.store(on ? 1 : 0); }
 // fp32-storage modes (f32 / bf16x3), read once (A/B builds and tools/ only; the workspace plan of a batch depends on them):
 //   KDIP_STORE_DZ (default 0): the backward-statistics epilogue of a dgrad conv leaves dz = dy * silu'(z) instead of dy (the second write of the
 //                              tensor measured +24 us on the 128 -> 128 @ 256^2 dgrad launches: the consumers apply silu' themselves instead)
@@ -359,6 +362,17 @@ struct Ctx {
   }
 };
 
+// 1: a forward conv with fused deterministic statistics leaves their finish pass to the GroupNorm that consumes them, which runs it inside its coefficient
+// kernel (conv_stats_finish_coef): one launch less in the dependency chain between two convs (kdip_debug / A-B switch: KDIP_DEFER_FINISH=0)
+// run the finish pass of `sums` now if its producer deferred it
+int finish_pending(Ctx& c, const double* sums, int B) {
+  bool dry = c.dry;
+  auto it = c.u->pending_stats.find(sums);
+  if (it == c.u->pending_stats.end()) return KDIP_OK;
+  RUN(conv_stats_finish(c.st, it->second, B, (double*)sums));
+  c.u->pending_stats.erase(it);
+  return KDIP_OK;
+}
 double* new_sums(Ctx& c, int B) { return (double*)c.u->zeros.alloc(sizeof(double) * B * 64); }
 
 // deterministic modes: a slab for one launch's block partials (scratch arena: transient, planned by the dry run like every other
@@ -408,10 +422,12 @@ int gn_forward(Ctx& c, const void* x, long ldx, int B, long HW, const GnW& g, co
       auto hi = c.u->fused_stats.find(std::make_pair((const void*)((const char*)x + c.es * C1), C2));
       if (hi == c.u->fused_stats.end()) continue;
       if (do_fold) {      // merged by the conv while it loads its table; the merged sums are still reserved, so that the workspace
+        { int rc_ = finish_pending(c, lo->second, B); if (rc_) return rc_; rc_ = finish_pending(c, hi->second, B); if (rc_) return rc_; }
         (void)new_sums(c, B);   // plan of a batch does not depend on the state of the fold switch when it was made (kdip_debug_gn_fold)
         stats = lo->second; stats2 = hi->second; mC1 = C1; break;
       }
       stats = new_sums(c, B);
+      { int rc_ = finish_pending(c, lo->second, B); if (rc_) return rc_; rc_ = finish_pending(c, hi->second, B); if (rc_) return rc_; }
       RUN(gn_merge_stats(c.st, lo->second, C1, hi->second, C2, B, stats));
       break;
     }
@@ -423,12 +439,22 @@ int gn_forward(Ctx& c, const void* x, long ldx, int B, long HW, const GnW& g, co
     RUN(gn_stats(c.st, c.dt, x, ldx, B, HW, g.C, stats, 1, dd ? &dw : nullptr));
   }
   if (do_fold) {
+    { int rc_ = finish_pending(c, stats, B); if (rc_) return rc_; }
     fold->fold_stats = stats; fold->fold_stats2 = stats2; fold->fold_C1 = mC1; fold->fold_gamma = g.gamma; fold->fold_beta = g.beta;
     fold->fold_film = film; fold->fold_film_ld = film_ld; fold->fold_HW = HW; fold->fold_eps = 1e-5f;
     fold->fold_coef_out = coef; fold->fold_mr_out = mr;
     return KDIP_OK;
   }
-  RUN(gn_coef(c.st, stats, g.gamma, g.beta, film, B, HW, g.C, 1e-5f, coef, mr, film_ld));
+  {
+    auto pd = c.u->pending_stats.find(stats);
+    if (pd != c.u->pending_stats.end() && !do_fold) {      // finish pass + coefficients in one launch
+      RUN(conv_stats_finish_coef(c.st, pd->second, B, stats, g.gamma, g.beta, film, film_ld, HW, g.C, 1e-5f, coef, mr));
+      c.u->pending_stats.erase(pd);
+    } else {
+      { int rc_ = finish_pending(c, stats, B); if (rc_) return rc_; }
+      RUN(gn_coef(c.st, stats, g.gamma, g.beta, film, B, HW, g.C, 1e-5f, coef, mr, film_ld));
+    }
+  }
   if (!y) return KDIP_OK;
   if (pool_W > 0) RUN(gn_apply_pool2(c.st, c.dt, x, ldx, coef, B, (int)(HW / pool_W), pool_W, g.C, silu, y, ldy, pool_x, g.C));
   else RUN(gn_apply(c.st, c.dt, x, ldx, coef, B, HW, g.C, silu, y, ldy));
@@ -510,17 +536,23 @@ int conv_f(Ctx& c, const ConvW& w, const void* x, long ldx, int B, int H, int W,
   stt.in_ups = in_ups; stt.res_ups = res_ups;
   if (tf_coef) { stt.tf_coef = tf_coef; stt.tf_silu = 1; }
   DetWs dw;
+  DetPending pend;
   if (stats_ok) {
     stt.mode = 1;
     stt.sums = new_sums(c, B);
     c.u->fused_stats[std::make_pair((const void*)y, w.cout)] = stt.sums;
-    if (det_ws(c, det_conv_bytes(B, H, W, w.cout), dw)) stt.det = &dw;
+    if (c.u->det) {      // the slab outlives this launch (persist arena, whatever the switch says: the workspace plan of a batch must not depend on it): the
+      dw.slab_bytes = det_conv_bytes(B, H, W, w.cout); dw.slab = c.u->persist.alloc(dw.slab_bytes);      // consuming GroupNorm runs the finish pass with its coefficient kernel
+      stt.det = &dw;
+      if (g_defer_finish.load()) stt.defer = &pend;
+    }
   }
   stt.sk_det = c.u->det ? 1 : 0;
   stt.x3_sat = c.u->x3_sat;
   stt.x3_lowpeak = c.peak_slot();
   RUN(conv_forward(c.st, c.cdt(), w.ntaps, x, ldx, B, H, W, w.cin_pad, c.wf(w), w.bias, w.cout, y, ldy, res, ldr, out_f32, 1.f, w.cin,
                    (stt.mode || in_ups || res_ups || tf_coef || stt.sk_det || stt.x3_sat) ? &stt : nullptr, c.u->sk_ws, c.u->sk_ws_floats));
+  if (stt.defer) c.u->pending_stats[stt.sums] = pend;      // (dry runs: an empty descriptor keeps the control flow of the consumers identical)
   return KDIP_OK;
 }
 // input-gradient: x here is dL/d(out) with >= cin_pad_b channels available (zero padded when cout % 32 != 0)
@@ -746,7 +778,7 @@ int UNet::forward_impl(hipStream_t st, const float* x_nchw, const float* t, int 
                        float* cov_nchw, float* feat_nchw) {
   Ctx c{this, st, dry, dt, esize()};
   const size_t es = esize();
-  persist.reset(); scratch.reset(); zeros.reset(); fused_stats.clear();
+  persist.reset(); scratch.reset(); zeros.reset(); fused_stats.clear(); pending_stats.clear();
   if (!dry && zeros.cap) KDIP_HIP_CHECK(hipMemsetAsync(zeros.base, 0, zeros.cap, st));
   {
     // split-K workspace: room for any 3x3 conv output (forward: cout, dgrad: cin channels) on a <= 16x16 map (the layers whose launches

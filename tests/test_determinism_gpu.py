@@ -126,3 +126,30 @@ def test_other_baseline_configs_bitwise_reproducible(dt, cid):
     assert torch.isfinite(a).all()
     nd = int((a != b).sum())
     assert nd == 0, (dt, cid, nd, float((a - b).abs().max()))
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16x3"])
+def test_deferred_statistics_finish_bit_identical(dtype):
+    """Deterministic modes: a forward conv with fused GroupNorm statistics leaves their fixed-order finish pass to the consuming GroupNorm, which runs it inside
+    its coefficient kernel (conv_stats_finish_coef: one launch less in the chain between two convs).  Same summation tree, same coefficient arithmetic:
+    UNet forward and input-VJP at the FFHQ shape are BITWISE those of the finish-behind-the-conv path (kdip_debug_defer_finish)."""
+    import kdip_amd._lib as L
+    import kdip_amd.unet as ku
+    lib = L.load()
+    sd = ku.synthetic_state_dict(seed=0, **ku.FFHQ_CONFIG)
+    m = ku.UNetModel(dtype=dtype, **ku.FFHQ_CONFIG)
+    m.load_state_dict(sd)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 3, 256, 256, generator=g).cuda()
+    t = torch.tensor([321.0, 47.0]).cuda()
+    cot = torch.randn(2, 6, 256, 256, generator=g).cuda()
+    res = {}
+    try:
+        for on in (1, 0):
+            L.check(lib.kdip_debug_defer_finish(on))
+            out, _, _ = m.forward_raw(x, t, in_scale=0.7)
+            res[on] = (out.clone(), m.vjp(cot).clone())
+    finally:
+        L.check(lib.kdip_debug_defer_finish(1))
+    assert torch.isfinite(res[1][0]).all() and torch.isfinite(res[1][1]).all()
+    assert torch.equal(res[1][0], res[0][0]) and torch.equal(res[1][1], res[0][1])
